@@ -1,0 +1,268 @@
+// huff_core.h -- per-block Huffman stage of the chunk compressor (zlib's _tr_flush_block as it
+// runs under consumer(), compression.cpp:131): exact emulation of zlib's heap-built trees
+// (tie-break on depth), length limiting, code-length RLE, and the stored / static / dynamic
+// decision.  SURVEY.md Appendix B "Block flush", "Tree build", "Length RLE".
+//
+// Portable (host + device).  Everything here is sequential per block; the device runs one
+// block per wave with the scratch in LDS.
+#pragma once
+#include "zwz_common.h"
+
+namespace zwz {
+
+struct TreeScratch {
+    // heap entries pack (freq:16 | depth:6 | node:10): smaller(n,m) == (key(n) <= key(m)) on the
+    // (freq, depth) part, which is exactly zlib's comparison
+    uint32_t heap[kHeapSize + 1];
+    uint16_t freq[kHeapSize];
+    uint16_t dad[kHeapSize];
+    uint8_t depth[kHeapSize];
+    uint8_t len[kHeapSize];
+    uint16_t bl_count[16];
+};
+
+struct BlockCodes {
+    uint8_t llen[kLCodes + 2];    // lit/len code lengths (0 = unused)
+    uint16_t lcode[kLCodes + 2];  // bit-reversed codes
+    uint8_t dlen[kDCodes + 2];
+    uint16_t dcode[kDCodes + 2];
+    uint8_t bllen[kBLCodes];
+    uint16_t blcode[kBLCodes];
+    int32_t l_max_code, d_max_code, max_blindex;
+    uint32_t opt_len, static_len;   // bits
+};
+
+ZWZ_HD uint32_t heap_key(uint32_t e) { return e >> 10; }
+
+ZWZ_HD void heap_sift(uint32_t* heap, int heap_len, int k) {
+    uint32_t v = heap[k];
+    int j = k << 1;
+    while (j <= heap_len) {
+        if (j < heap_len && heap_key(heap[j + 1]) <= heap_key(heap[j])) j++;
+        if (heap_key(v) <= heap_key(heap[j])) break;
+        heap[k] = heap[j]; k = j; j <<= 1;
+    }
+    heap[k] = v;
+}
+
+// zlib build_tree + gen_bitlen + gen_codes.  freq_in[0..elems) are the symbol counts; lens/codes
+// receive the result.  extra_bits(sym) / static_len_of(sym) feed opt_len / static_len.
+// Returns max_code.  opt_len/static_len are updated in place (may be decremented for forced codes).
+template <class ExtraFn, class StatFn>
+ZWZ_HD int build_tree(TreeScratch& s, const uint16_t* freq_in, int elems, int max_length, ExtraFn extra_bits,
+                      StatFn static_len_of, bool has_static, uint8_t* lens, uint16_t* codes, uint32_t& opt_len,
+                      uint32_t& static_len) {
+    int heap_len = 0, heap_max = (int)kHeapSize, max_code = -1;
+    for (int n = 0; n < elems; n++) {
+        s.freq[n] = freq_in[n];
+        s.len[n] = 0;
+        if (freq_in[n] != 0) { max_code = n; s.depth[n] = 0; s.heap[++heap_len] = ((uint32_t)freq_in[n] << 16) | (uint32_t)n; }
+    }
+    while (heap_len < 2) {
+        int node = max_code < 2 ? ++max_code : 0;
+        s.freq[node] = 1; s.depth[node] = 0;
+        s.heap[++heap_len] = (1u << 16) | (uint32_t)node;
+        opt_len--;
+        if (has_static) static_len -= static_len_of((uint32_t)node);
+    }
+    for (int n = heap_len / 2; n >= 1; n--) heap_sift(s.heap, heap_len, n);
+    // the sorted tail shares the array with the heap (zlib's layout): heap[heap_max..kHeapSize)
+    int node = elems;
+    do {
+        uint32_t en = s.heap[1];
+        s.heap[1] = s.heap[heap_len--];
+        heap_sift(s.heap, heap_len, 1);
+        uint32_t em = s.heap[1];
+        uint32_t n = en & 1023u, m = em & 1023u;
+        s.heap[--heap_max] = n; s.heap[--heap_max] = m;
+        uint32_t f = (uint32_t)s.freq[n] + s.freq[m];
+        uint32_t d = (s.depth[n] >= s.depth[m] ? s.depth[n] : s.depth[m]) + 1u;
+        s.freq[node] = (uint16_t)f; s.depth[node] = (uint8_t)d;
+        s.dad[n] = s.dad[m] = (uint16_t)node;
+        s.heap[1] = (f << 16) | (d << 10) | (uint32_t)node;
+        node++;
+        heap_sift(s.heap, heap_len, 1);
+    } while (heap_len >= 2);
+    s.heap[--heap_max] = s.heap[1] & 1023u;
+
+    // gen_bitlen
+    for (int b = 0; b < 16; b++) s.bl_count[b] = 0;
+    int overflow = 0, h;
+    s.len[s.heap[heap_max]] = 0;
+    for (h = heap_max + 1; h < (int)kHeapSize; h++) {
+        uint32_t n = s.heap[h];
+        int bits = s.len[s.dad[n]] + 1;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        s.len[n] = (uint8_t)bits;
+        if ((int)n > max_code) continue;
+        s.bl_count[bits]++;
+        uint32_t f = s.freq[n];
+        opt_len += f * ((uint32_t)bits + extra_bits(n));
+        if (has_static) static_len += f * (static_len_of(n) + extra_bits(n));
+    }
+    if (overflow > 0) {
+        do {
+            int bits = max_length - 1;
+            while (s.bl_count[bits] == 0) bits--;
+            s.bl_count[bits]--; s.bl_count[bits + 1] += 2; s.bl_count[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (int bits = max_length; bits != 0; bits--) {
+            int n = s.bl_count[bits];
+            while (n != 0) {
+                uint32_t m = s.heap[--h];
+                if ((int)m > max_code) continue;
+                if (s.len[m] != (uint32_t)bits) {
+                    opt_len += ((uint32_t)bits - s.len[m]) * s.freq[m];
+                    s.len[m] = (uint8_t)bits;
+                }
+                n--;
+            }
+        }
+    }
+    // gen_codes
+    uint32_t next_code[16], code = 0;
+    next_code[0] = 0;
+    for (int b = 1; b <= 15; b++) { code = (code + s.bl_count[b - 1]) << 1; next_code[b] = code; }
+    for (int n = 0; n < elems; n++) {
+        uint32_t l = n <= max_code ? s.len[n] : 0;
+        lens[n] = (uint8_t)l;
+        codes[n] = l ? (uint16_t)bit_reverse(next_code[l]++, l) : 0;
+    }
+    return max_code;
+}
+
+// Code-length RLE over lens[0..max_code] (zlib scan_tree / send_tree).  sink(sym, extra_val,
+// extra_nbits) is called per emitted bl symbol.
+template <class Sink>
+ZWZ_HD void rle_lengths(const uint8_t* lens, int max_code, Sink sink) {
+    int prevlen = -1, curlen, nextlen = lens[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = n == max_code ? 0xffff : lens[n + 1];
+        if (++count < max_count && curlen == nextlen) continue;
+        if (count < min_count) {
+            do { sink((uint32_t)curlen, 0u, 0u); } while (--count != 0);
+        } else if (curlen != 0) {
+            if (curlen != prevlen) { sink((uint32_t)curlen, 0u, 0u); count--; }
+            sink(16u, (uint32_t)count - 3u, 2u);
+        } else if (count <= 10) {
+            sink(17u, (uint32_t)count - 3u, 3u);
+        } else {
+            sink(18u, (uint32_t)count - 11u, 7u);
+        }
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+        else { max_count = 7; min_count = 4; }
+    }
+}
+
+ZWZ_HD uint32_t bl_order(uint32_t i) {
+    // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+    return i < 3 ? 16u + i : i == 3 ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
+}
+
+enum BlockType : uint32_t { kStored = 0, kStatic = 1, kDynamic = 2 };
+
+// Little bit sink over 32-bit words (LSB first), used for the dynamic block header.
+struct BitSink {
+    uint32_t* words; uint32_t nbits;
+    ZWZ_HD void put(uint32_t v, uint32_t n) {
+        if (n == 0) return;
+        uint32_t w = nbits >> 5, o = nbits & 31u;
+        if (o == 0) words[w] = v;
+        else {
+            words[w] |= v << o;
+            if (o + n > 32) words[w + 1] = v >> (32u - o);
+        }
+        nbits += n;
+    }
+};
+
+constexpr uint32_t kHdrWords = 96;  // dynamic header <= 14 + 57 + 316*(7+7) bits < 3072 bits
+
+// Everything zlib decides when it flushes one block.  lfreq[286] (with lfreq[256] == 1) and
+// dfreq[30] are the block's symbol histograms; stored_len the raw bytes it covers; stored_ok is
+// false when zlib no longer has the block's bytes addressable (block began before a window slide).
+// Outputs: codes, block type, the dynamic header bits (incl. the 3 block-type bits; `last` goes
+// in bit 0), and the bit length of the block's symbol payload (incl. end-of-block) under the
+// chosen code.
+struct BlockPlan {
+    uint32_t type;          // BlockType
+    uint32_t hdr_bits;      // bits in hdr[] (3 for stored/static)
+    uint32_t body_bits;     // symbols + EOB under the chosen tree (0 for stored)
+};
+
+ZWZ_HD BlockPlan plan_block(TreeScratch& ts, const uint16_t* lfreq, const uint16_t* dfreq, uint32_t stored_len,
+                            bool stored_ok, uint32_t last, BlockCodes& bc, uint32_t* hdr /* kHdrWords */) {
+    bc.opt_len = 0; bc.static_len = 0;
+    bc.l_max_code = build_tree(ts, lfreq, (int)kLCodes, 15,
+                               [](uint32_t n) { return n >= 257u ? length_extra_bits(n - 257u) : 0u; },
+                               [](uint32_t n) { return static_lit_len(n); }, true, bc.llen, bc.lcode, bc.opt_len,
+                               bc.static_len);
+    bc.d_max_code = build_tree(ts, dfreq, (int)kDCodes, 15, [](uint32_t n) { return dist_extra_bits(n); },
+                               [](uint32_t) { return 5u; }, true, bc.dlen, bc.dcode, bc.opt_len, bc.static_len);
+    uint16_t blfreq[kBLCodes];
+    for (uint32_t i = 0; i < kBLCodes; i++) blfreq[i] = 0;
+    auto tally = [&](uint32_t sym, uint32_t, uint32_t) { blfreq[sym]++; };
+    rle_lengths(bc.llen, bc.l_max_code, tally);
+    rle_lengths(bc.dlen, bc.d_max_code, tally);
+    uint32_t dummy_static = 0;
+    build_tree(ts, blfreq, (int)kBLCodes, 7, [](uint32_t n) { return n < 16u ? 0u : n == 16u ? 2u : n == 17u ? 3u : 7u; },
+               [](uint32_t) { return 0u; }, false, bc.bllen, bc.blcode, bc.opt_len, dummy_static);
+    int mbi;
+    for (mbi = (int)kBLCodes - 1; mbi >= 3; mbi--)
+        if (bc.bllen[bl_order((uint32_t)mbi)] != 0) break;
+    bc.max_blindex = mbi;
+    bc.opt_len += 3u * ((uint32_t)mbi + 1u) + 5u + 5u + 4u;
+
+    uint32_t opt_lenb = (bc.opt_len + 3u + 7u) >> 3, static_lenb = (bc.static_len + 3u + 7u) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+
+    BlockPlan bp;
+    BitSink sink{hdr, 0};
+    if (stored_len + 4u <= opt_lenb && stored_ok) {
+        bp.type = kStored;
+        sink.put((0u << 1) + last, 3);
+        bp.body_bits = 0;
+    } else if (static_lenb == opt_lenb) {
+        bp.type = kStatic;
+        sink.put((1u << 1) + last, 3);
+        bp.body_bits = bc.static_len;
+        // re-express the codes as the static ones so the encoder needs no special case
+        for (uint32_t n = 0; n < kLCodes; n++) { bc.llen[n] = (uint8_t)static_lit_len(n); bc.lcode[n] = (uint16_t)static_lit_code(n); }
+        for (uint32_t n = 0; n < kDCodes; n++) { bc.dlen[n] = 5; bc.dcode[n] = (uint16_t)bit_reverse(n, 5); }
+    } else {
+        bp.type = kDynamic;
+        sink.put((2u << 1) + last, 3);
+        sink.put((uint32_t)(bc.l_max_code + 1 - 257), 5);
+        sink.put((uint32_t)(bc.d_max_code + 1 - 1), 5);
+        sink.put((uint32_t)(mbi + 1 - 4), 4);
+        for (int r = 0; r <= mbi; r++) sink.put(bc.bllen[bl_order((uint32_t)r)], 3);
+        auto send = [&](uint32_t sym, uint32_t xv, uint32_t xn) { sink.put(bc.blcode[sym], bc.bllen[sym]); sink.put(xv, xn); };
+        rle_lengths(bc.llen, bc.l_max_code, send);
+        rle_lengths(bc.dlen, bc.d_max_code, send);
+        // opt_len counts header + symbols + EOB; the symbol part is what remains
+        bp.body_bits = bc.opt_len - (sink.nbits - 3u);
+    }
+    bp.hdr_bits = sink.nbits;
+    return bp;
+}
+
+// Bits of one symbol under a block's codes, LSB-first.  Literal: entry == 0, lit = byte.
+// Match: entry = packed (len, dist).  At most 15+5+15+13 = 48 bits.
+ZWZ_HD void symbol_bits(const uint16_t* lcode, const uint8_t* llen, const uint16_t* dcode, const uint8_t* dlen,
+                        uint32_t entry, uint32_t lit, uint64_t& bits, uint32_t& nbits) {
+    if (entry == 0) { bits = lcode[lit]; nbits = llen[lit]; return; }
+    uint32_t lc = entry_len(entry) - kMinMatch, dm1 = entry_dist(entry) - 1u;
+    uint32_t c = length_code(lc), d = dist_code(dm1);
+    uint64_t v = lcode[257u + c];
+    uint32_t n = llen[257u + c];
+    v |= (uint64_t)(lc - length_base(c)) << n; n += length_extra_bits(c);
+    v |= (uint64_t)dcode[d] << n; n += dlen[d];
+    v |= (uint64_t)(dm1 - dist_base(d)) << n; n += dist_extra_bits(d);
+    bits = v; nbits = n;
+}
+
+}  // namespace zwz
