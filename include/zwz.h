@@ -1,0 +1,116 @@
+/*
+ * zwz.h -- C ABI of the MI355X-native chunk codec: the drop-in boundary for the reference's hot path.
+ *
+ * The reference (JoernZheng/parallel-data-compression-and-decompression) has no plugin/FFI
+ * surface; its seams are C++ prototypes in process.hpp:37-42 and two inline zlib call sites.
+ * Each entry point below names the reference interface it replaces:
+ *
+ *   zwz_deflate_batch*     the zlib call pair in consumer(), compression.cpp:119-134
+ *                          (deflateInit level 6 / deflate(Z_FINISH) into a 65535-byte buffer /
+ *                          deflateEnd), once per Chunk (process.hpp:21-28) -- here for a batch
+ *   zwz_inflate_batch*     decompress_chunk(), decompression.cpp:11-37 (inflateInit / inflate
+ *                          loop / inflateEnd, return codes ignored), once per CompressedChunk
+ *                          (process.hpp:30-35) -- here for a batch
+ *   zwz_compress_dir       do_compression(input_dir, output_dir, file_record, world_rank),
+ *                          process.hpp:39 / compression.cpp:161-194 (+ the rank < file_count
+ *                          guard of compress(), main.cpp:44-51)
+ *   zwz_decompress_dir     do_decompression(input_dir, output_dir), process.hpp:40 /
+ *                          decompression.cpp:165-178
+ *   zwz_sort_files_by_size sort_files_by_size(path), process.hpp:37 / file_sort.cpp:24-43
+ *   zwz_count_non_empty_lines  count_non_empty_lines(file), process.hpp:38 / file_tools.cpp:6-23
+ *   zwz_md5_of_file        md5_of_file(path), process.hpp:41 / verification.cpp:6-30
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the boundary, 0 = success and
+ * negative zwz_status codes otherwise, caller owns every buffer.  A context binds one GPU, one
+ * HIP stream and a device workspace; calls on one context are serialised by the caller, distinct
+ * contexts are independent.  There is no CPU fallback: without a usable GPU zwz_ctx_create fails.
+ *
+ * Bit-exactness contract: for every chunk, out[0..out_len) equals the first min(len, 65535)
+ * bytes of zlib 1.2.11's level-6 stream of that chunk -- what the reference stores in a .zwz
+ * record.
+ */
+#ifndef ZWZ_H
+#define ZWZ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZWZ_CHUNK_SIZE 65535u      /* process.hpp:12 CHUNK_SIZE */
+#define ZWZ_DEV_STRIDE 65536u      /* chunk slot stride in device buffers (16-byte aligned slots) */
+#define ZWZ_MD5_HEX_LEN 32u        /* process.hpp:14 MD5_DATA_SIZE */
+
+typedef enum zwz_status {
+    ZWZ_OK = 0,
+    ZWZ_E_INVALID = -1,   /* bad argument (null pointer, misaligned device slot, size > 65535) */
+    ZWZ_E_HIP = -2,       /* a HIP runtime call failed; zwz_last_error() has the text */
+    ZWZ_E_NO_DEVICE = -3, /* no usable gfx950 device */
+    ZWZ_E_IO = -4,        /* file system error */
+    ZWZ_E_NOMEM = -5,
+    ZWZ_E_FORMAT = -6     /* malformed .zwz shard */
+} zwz_status;
+
+/* Per-chunk status written by the inflate entry points (the reference ignores zlib's return
+ * codes, decompression.cpp:31; these only report, they never suppress output). */
+typedef enum zwz_inflate_status {
+    ZWZ_INF_END = 0,         /* final block reached */
+    ZWZ_INF_NEED_INPUT = 1,  /* payload ended early (reference-truncated chunk): partial output kept */
+    ZWZ_INF_DATA_ERROR = 2,  /* invalid stream: output up to the error kept */
+    ZWZ_INF_OVERFLOW = 3     /* stream decodes past 65535 bytes (not producible by the reference) */
+} zwz_inflate_status;
+
+typedef struct zwz_ctx zwz_ctx;
+
+const char *zwz_strerror(int status);
+const char *zwz_last_error(void);               /* thread-local detail for ZWZ_E_HIP / ZWZ_E_IO */
+int zwz_device_count(int *count);
+
+/* max_batch_chunks bounds the device workspace (~680 KiB per chunk); larger batches are
+ * processed in slices.  0 selects the default (8192). */
+int zwz_ctx_create(int device, uint32_t max_batch_chunks, zwz_ctx **ctx);
+void zwz_ctx_destroy(zwz_ctx *ctx);
+void *zwz_ctx_stream(zwz_ctx *ctx);             /* the context's hipStream_t */
+int zwz_ctx_sync(zwz_ctx *ctx);
+
+/* ---- device-resident batches (asynchronous on the context's stream) ------------------------
+ * d_in + d_in_off[i] is chunk i (d_in_len[i] <= 65535 bytes, d_in_off[i] % 16 == 0 for deflate).
+ * Chunk i's result goes to d_out + i * out_stride (out_stride % 16 == 0, >= 65536) with its
+ * length in d_out_len[i].  All pointers are device memory on the context's GPU. */
+int zwz_deflate_batch_dev(zwz_ctx *ctx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                          uint32_t n, uint8_t *d_out, uint64_t out_stride, uint32_t *d_out_len);
+int zwz_inflate_batch_dev(zwz_ctx *ctx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                          uint32_t n, uint8_t *d_out, uint64_t out_stride, uint32_t *d_out_len, uint32_t *d_status);
+
+/* ---- host-buffer batches (synchronous; staged through pinned memory) ------------------------
+ * in + in_off[i] is chunk i; results at out + i * 65535, lengths in out_len[i]. */
+int zwz_deflate_batch(zwz_ctx *ctx, const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t n,
+                      uint8_t *out, uint32_t *out_len);
+int zwz_inflate_batch(zwz_ctx *ctx, const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t n,
+                      uint8_t *out, uint32_t *out_len, uint32_t *status);
+
+/* ---- stage timing (HIP events on the context's stream) -------------------------------------
+ * With profiling on, every deflate slice records events around its 6 kernels; the accumulated
+ * milliseconds since the last reset are returned in ms[0..6) in pipeline order
+ * (links, match, parse, blockify, plan, encode), ms[6] = inflate kernel. */
+#define ZWZ_NUM_STAGES 7
+int zwz_ctx_set_profiling(zwz_ctx *ctx, int on);
+int zwz_ctx_stage_ms(zwz_ctx *ctx, float *ms, int reset);
+
+/* ---- directory level (the reference's per-rank pipeline) ------------------------------------ */
+int zwz_sort_files_by_size(const char *src_dir, char *record_path_out, size_t cap);
+int zwz_count_non_empty_lines(const char *file_path);
+int zwz_md5_of_file(const char *path, char hex_out[33]);
+/* Shard `rank` of `nranks`: lines i of file_record with i % nranks == rank, written to
+ * <dst>/compressed_<rank>.zwz.  Ranks >= the number of listed files write nothing. */
+int zwz_compress_dir(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, const char *file_record, int rank,
+                     int nranks);
+/* Every <src>/ *.zwz -> files under <dst>; md5_mismatches (optional) counts files whose MD5
+ * differs from the stored one (the reference only prints them, decompression.cpp:140-146). */
+int zwz_decompress_dir(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, int *md5_mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

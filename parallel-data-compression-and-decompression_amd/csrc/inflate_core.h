@@ -1,0 +1,231 @@
+// inflate_core.h -- chunk decoder behind decompress_chunk() (decompression.cpp:11-37): zlib
+// header check, RFC 1951 block decoding, and the reference's "return codes ignored" semantics:
+// output = everything zlib emits before it stops (stream end, input exhausted -- the reference
+// truncates payloads at 65535 bytes, compression.cpp:127-132 -- or a data error); the Adler-32
+// trailer never rejects (Inflate).
+//
+// Portable (host + device).  Decoding one Huffman stream is sequential, so the device gives a
+// chunk to one wave: lane 0 runs the functions below and hands batches of decoded symbols to the
+// whole wave, which does the byte moving (literal scatter, LZ copies, stored-block copies).
+#pragma once
+#include "zwz_common.h"
+
+namespace zwz {
+
+constexpr uint32_t kLitFastBits = 10, kDistFastBits = 8;
+constexpr uint32_t kBatch = 64;
+
+enum InflateStatus : uint32_t {
+    kInfEnd = 0,        // final block decoded (trailer not checked here)
+    kInfNeedInput = 1,  // payload ended early: truncated by the reference, or incomplete
+    kInfDataError = 2,  // invalid stream
+    kInfOverflow = 3,   // would produce more than the 65535-byte slot
+    kInfRunning = 4
+};
+
+// Decoding tables of one block, built by lane 0 into LDS.
+struct InflateTables {
+    uint16_t lit_fast[1u << kLitFastBits];   // (sym << 4) | len, 0 = code longer than the index or invalid
+    uint16_t dist_fast[1u << kDistFastBits];
+    uint16_t lit_count[16], dist_count[16];  // canonical fallback: codes per length
+    uint16_t lit_sym[288], dist_sym[32];     // symbols sorted by (length, symbol)
+};
+
+struct BitReader {
+    const uint8_t* in; uint32_t n, pos;
+    uint64_t hold; uint32_t bits;
+    ZWZ_HD void init(const uint8_t* p, uint32_t len) { in = p; n = len; pos = 0; hold = 0; bits = 0; }
+    // top up to >= 56 bits while input lasts
+    ZWZ_HD void refill() {
+        while (bits <= 56 && pos < n) { hold |= (uint64_t)in[pos++] << bits; bits += 8; }
+    }
+    ZWZ_HD uint32_t peek(uint32_t k) const { return (uint32_t)(hold & ((1ull << k) - 1ull)); }
+    ZWZ_HD void drop(uint32_t k) { hold >>= k; bits -= k; }
+    ZWZ_HD bool take(uint32_t k, uint32_t& v) {  // all-or-nothing
+        if (bits < k) { refill(); if (bits < k) return false; }
+        v = peek(k); drop(k);
+        return true;
+    }
+};
+
+// Build fast + canonical tables from code lengths.  Returns 0 ok, -1 over-subscribed,
+// 1 incomplete (caller decides whether that is legal).  max_len receives the longest code.
+ZWZ_HD int build_decode_table(const uint8_t* lens, uint32_t n, uint16_t* fast, uint32_t fast_bits, uint16_t* count,
+                              uint16_t* sorted, uint32_t& max_len) {
+    uint16_t offs[16];
+    for (uint32_t l = 0; l < 16; l++) count[l] = 0;
+    for (uint32_t i = 0; i < n; i++) count[lens[i]]++;
+    count[0] = 0;
+    max_len = 0;
+    int left = 1;
+    for (uint32_t l = 1; l < 16; l++) {
+        if (count[l]) max_len = l;
+        left <<= 1; left -= count[l];
+        if (left < 0) return -1;
+    }
+    offs[1] = 0;
+    for (uint32_t l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+    for (uint32_t i = 0; i < n; i++) if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
+    for (uint32_t i = 0; i < (1u << fast_bits); i++) fast[i] = 0;
+    // canonical codes in (length, symbol) order; entries replicated over the unused high bits
+    uint32_t code = 0, idx = 0;
+    for (uint32_t l = 1; l <= fast_bits; l++) {
+        for (uint32_t k = 0; k < count[l]; k++, idx++, code++) {
+            uint32_t rev = bit_reverse(code, l);
+            uint16_t e = (uint16_t)((sorted[idx] << 4) | l);
+            for (uint32_t j = rev; j < (1u << fast_bits); j += 1u << l) fast[j] = e;
+        }
+        code <<= 1;
+    }
+    return left > 0 ? 1 : 0;
+}
+
+// Decode one symbol.  Returns symbol >= 0, -1 if the payload ends inside the code (nothing
+// consumed), -2 if the bits match no code.
+ZWZ_HD int decode_symbol(BitReader& br, const uint16_t* fast, uint32_t fast_bits, const uint16_t* count,
+                         const uint16_t* sorted) {
+    if (br.bits < 15) br.refill();
+    uint32_t e = fast[br.peek(fast_bits)];
+    uint32_t l = e & 15u;
+    if (e != 0 && l <= br.bits) { br.drop(l); return (int)(e >> 4); }
+    // slow path: canonical walk bit by bit (long codes, invalid codes, or the stream's last bits)
+    int code = 0, first = 0, index = 0;
+    for (uint32_t len = 1; len <= 15; len++) {
+        if (br.bits < len) return -1;
+        code |= (int)((br.hold >> (len - 1)) & 1u);
+        int c = count[len];
+        if (code - c < first) { br.drop(len); return sorted[index + (code - first)]; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -2;
+}
+
+struct InflateState {
+    BitReader br;
+    uint32_t out_pos;       // bytes produced so far
+    uint32_t last;          // current block is final
+    uint32_t status;        // InflateStatus
+};
+
+// zlib stream header (RFC 1950).  Returns false (status set) if decoding cannot start.
+ZWZ_HD bool inflate_begin(InflateState& st, const uint8_t* in, uint32_t n) {
+    st.br.init(in, n); st.out_pos = 0; st.last = 0; st.status = kInfRunning;
+    uint32_t cmf, flg;
+    if (!st.br.take(8, cmf) || !st.br.take(8, flg)) { st.status = kInfNeedInput; return false; }
+    if (((cmf << 8) + flg) % 31u || (cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 0x20u)) { st.status = kInfDataError; return false; }
+    return true;
+}
+
+enum BlockKind : uint32_t { kBlkStored = 0, kBlkHuffman = 1, kBlkStop = 2 };
+
+// Read one block header.  Stored: returns kBlkStored with (src_off, len) = bytes to copy from
+// the payload (clipped to what the payload holds: a clipped stored block also sets status
+// NeedInput).  Huffman: tables are built, returns kBlkHuffman.  kBlkStop: status says why.
+ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t* lens /* 320 B scratch */,
+                                     uint32_t& src_off, uint32_t& len) {
+    BitReader& br = st.br;
+    uint32_t v;
+    if (!br.take(1, st.last)) { st.status = kInfNeedInput; return kBlkStop; }
+    if (!br.take(2, v)) { st.status = kInfNeedInput; return kBlkStop; }
+    if (v == 0) {
+        br.drop(br.bits & 7u);
+        uint32_t a, b;
+        // LEN/NLEN: zlib needs all 32 bits before it copies anything
+        if (br.bits + 8u * (br.n - br.pos) < 32u) { st.status = kInfNeedInput; return kBlkStop; }
+        br.take(16, a); br.take(16, b);
+        if ((a ^ 0xffffu) != b) { st.status = kInfDataError; return kBlkStop; }
+        // give back whole bytes still in the bit buffer: the block body is byte-addressed
+        br.pos -= br.bits >> 3; br.hold = 0; br.bits = 0;
+        uint32_t avail = br.n - br.pos;
+        src_off = br.pos;
+        len = a < avail ? a : avail;
+        br.pos += len;
+        if (len < a) st.status = kInfNeedInput;
+        return kBlkStored;
+    }
+    if (v == 3) { st.status = kInfDataError; return kBlkStop; }
+    uint32_t nlen, ndist, max_len;
+    if (v == 1) {
+        nlen = 288; ndist = 30;
+        for (uint32_t i = 0; i < 288; i++) lens[i] = (uint8_t)static_lit_len(i);
+        for (uint32_t i = 0; i < 30; i++) lens[288 + i] = 5;
+        build_decode_table(lens, 288, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len);
+        build_decode_table(lens + 288, 30, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len);
+        return kBlkHuffman;
+    }
+    uint32_t ncode;
+    if (br.bits < 14) br.refill();
+    if (br.bits < 14) { st.status = kInfNeedInput; return kBlkStop; }
+    br.take(5, nlen); br.take(5, ndist); br.take(4, ncode);
+    nlen += 257; ndist += 1; ncode += 4;
+    if (nlen > 286 || ndist > 30) { st.status = kInfDataError; return kBlkStop; }
+    uint8_t cl[19];
+    for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
+    for (uint32_t i = 0; i < ncode; i++) {
+        if (!br.take(3, v)) { st.status = kInfNeedInput; return kBlkStop; }
+        uint32_t o = i < 3 ? 16u + i : i == 3 ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
+        cl[o] = (uint8_t)v;
+    }
+    // the code-length code reuses the distance-table slots (7-bit fast index fits in 8)
+    if (build_decode_table(cl, 19, t.dist_fast, 7, t.dist_count, t.dist_sym, max_len) != 0) { st.status = kInfDataError; return kBlkStop; }
+    uint32_t have = 0;
+    while (have < nlen + ndist) {
+        BitReader save = br;
+        int sym = decode_symbol(br, t.dist_fast, 7, t.dist_count, t.dist_sym);
+        if (sym == -1) { st.status = kInfNeedInput; return kBlkStop; }
+        if (sym == -2) { st.status = kInfDataError; return kBlkStop; }
+        if (sym < 16) { lens[have++] = (uint8_t)sym; continue; }
+        uint32_t prev = 0, rep, xb = sym == 16 ? 2u : sym == 17 ? 3u : 7u, xv;
+        if (!br.take(xb, xv)) { br = save; st.status = kInfNeedInput; return kBlkStop; }
+        if (sym == 16) {
+            if (have == 0) { st.status = kInfDataError; return kBlkStop; }
+            prev = lens[have - 1]; rep = 3u + xv;
+        } else rep = (sym == 17 ? 3u : 11u) + xv;
+        if (have + rep > nlen + ndist) { st.status = kInfDataError; return kBlkStop; }
+        while (rep--) lens[have++] = (uint8_t)prev;
+    }
+    if (lens[256] == 0) { st.status = kInfDataError; return kBlkStop; }
+    int lr = build_decode_table(lens, nlen, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len);
+    if (lr < 0 || (lr > 0 && max_len != 1)) { st.status = kInfDataError; return kBlkStop; }
+    int dr = build_decode_table(lens + nlen, ndist, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len);
+    if (dr < 0 || (dr > 0 && max_len > 1)) { st.status = kInfDataError; return kBlkStop; }
+    return kBlkHuffman;
+}
+
+// Decode up to kBatch symbols of the current Huffman block.  batch[i] = literal byte, or
+// (len << 16) | dist for a match (dist >= 1).  pos[i] = output offset of symbol i.
+// Returns the symbol count; *block_done is set at end-of-block or when decoding stops.
+// out_cap bounds the output slot (65535): a symbol that would cross it stops with kInfOverflow.
+ZWZ_HD uint32_t inflate_decode_batch(InflateState& st, const InflateTables& t, uint32_t out_cap, uint32_t* batch,
+                                     uint32_t* pos, bool& block_done) {
+    BitReader& br = st.br;
+    uint32_t k = 0;
+    block_done = false;
+    while (k < kBatch) {
+        int sym = decode_symbol(br, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym);
+        if (sym < 0) { st.status = sym == -1 ? kInfNeedInput : kInfDataError; block_done = true; break; }
+        if (sym < 256) {
+            if (st.out_pos >= out_cap) { st.status = kInfOverflow; block_done = true; break; }
+            batch[k] = (uint32_t)sym; pos[k] = st.out_pos; k++; st.out_pos++;
+            continue;
+        }
+        if (sym == 256) { block_done = true; break; }
+        uint32_t c = (uint32_t)sym - 257u;
+        if (c >= 29u) { st.status = kInfDataError; block_done = true; break; }
+        uint32_t xv = 0, xb = length_extra_bits(c);
+        if (!br.take(xb, xv)) { st.status = kInfNeedInput; block_done = true; break; }
+        uint32_t len = (c == 28u ? 258u : length_base(c) + 3u + xv);
+        int ds = decode_symbol(br, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym);
+        if (ds < 0) { st.status = ds == -1 ? kInfNeedInput : kInfDataError; block_done = true; break; }
+        if (ds >= 30) { st.status = kInfDataError; block_done = true; break; }
+        xb = dist_extra_bits((uint32_t)ds);
+        if (!br.take(xb, xv)) { st.status = kInfNeedInput; block_done = true; break; }
+        uint32_t dist = dist_base((uint32_t)ds) + 1u + xv;
+        if (dist > st.out_pos) { st.status = kInfDataError; block_done = true; break; }  // too far back
+        if (st.out_pos + len > out_cap) { st.status = kInfOverflow; block_done = true; break; }
+        batch[k] = (len << 16) | dist; pos[k] = st.out_pos; k++; st.out_pos += len;
+    }
+    return k;
+}
+
+}  // namespace zwz

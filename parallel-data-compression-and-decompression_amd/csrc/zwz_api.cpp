@@ -1,0 +1,255 @@
+// zwz_api.cpp -- C ABI (include/zwz.h) over the kernel pipeline: context, workspace, batch slicing,
+// pinned staging for host buffers.  No CPU codec lives here: without a GPU every entry point fails.
+#include "zwz_api_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace zwz {
+
+thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return ZWZ_E_HIP;
+}
+
+}  // namespace zwz
+
+using namespace zwz;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+extern "C" {
+
+const char* zwz_strerror(int s) {
+    switch (s) {
+        case ZWZ_OK: return "ok";
+        case ZWZ_E_INVALID: return "invalid argument";
+        case ZWZ_E_HIP: return "HIP runtime error";
+        case ZWZ_E_NO_DEVICE: return "no usable GPU (this library has no CPU fallback)";
+        case ZWZ_E_IO: return "I/O error";
+        case ZWZ_E_NOMEM: return "out of memory";
+        case ZWZ_E_FORMAT: return "malformed .zwz shard";
+        default: return "unknown status";
+    }
+}
+
+const char* zwz_last_error(void) { return g_err; }
+
+int zwz_device_count(int* count) {
+    if (!count) return ZWZ_E_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return ZWZ_E_NO_DEVICE; }
+    *count = n;
+    return ZWZ_OK;
+}
+
+int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
+    if (!out) return ZWZ_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (zwz_device_count(&n) != ZWZ_OK || n <= 0) { set_error("hipGetDeviceCount found no device"); return ZWZ_E_NO_DEVICE; }
+    if (device < 0 || device >= n) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(device));
+    zwz_ctx* c = new (std::nothrow) zwz_ctx();
+    if (!c) return ZWZ_E_NOMEM;
+    c->device = device;
+    c->max_batch = max_batch ? max_batch : 8192u;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = configure_kernels();
+    if (e == hipSuccess) e = hipMalloc(&c->workspace, (size_t)c->max_batch * kWorkspaceBytesPerChunk + 4096);
+    for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
+    if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create"); zwz_ctx_destroy(c); return rc; }
+    *out = c;
+    return ZWZ_OK;
+}
+
+void zwz_ctx_destroy(zwz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->workspace) (void)hipFree(c->workspace);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_inf) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* zwz_ctx_stream(zwz_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int zwz_ctx_sync(zwz_ctx* c) {
+    if (!c) return ZWZ_E_INVALID;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ZWZ_OK;
+}
+
+int zwz_ctx_set_profiling(zwz_ctx* c, int on) {
+    if (!c) return ZWZ_E_INVALID;
+    c->profiling = on != 0;
+    return ZWZ_OK;
+}
+
+int zwz_ctx_stage_ms(zwz_ctx* c, float* ms, int reset) {
+    if (!c || !ms) return ZWZ_E_INVALID;
+    for (int i = 0; i < ZWZ_NUM_STAGES; i++) ms[i] = c->stage_ms[i];
+    if (reset) for (auto& v : c->stage_ms) v = 0.f;
+    return ZWZ_OK;
+}
+
+int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                          uint8_t* d_out, uint64_t out_stride, uint32_t* d_out_len) {
+    if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len))) return ZWZ_E_INVALID;
+    if (out_stride < ZWZ_DEV_STRIDE || (out_stride & 15u) || ((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t done = 0; done < n; done += c->max_batch) {
+        const uint32_t m = n - done < c->max_batch ? n - done : c->max_batch;
+        DeflateArgs a;
+        a.in = d_in; a.in_off = d_in_off + done; a.in_len = d_in_len + done; a.n = m;
+        a.out = d_out + (size_t)done * out_stride; a.out_stride = out_stride; a.out_len = d_out_len + done;
+        carve_workspace(c, a);
+        HIPCHK(launch_deflate(a, c->stream, c->profiling ? c->ev : nullptr));
+        if (c->profiling) {   // profiling serialises slices: stage times are read back per slice
+            HIPCHK(hipEventSynchronize(c->ev[kNumDeflateStages]));
+            for (int i = 0; i < kNumDeflateStages; i++) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+                c->stage_ms[i] += ms;
+            }
+        }
+    }
+    return ZWZ_OK;
+}
+
+int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                          uint8_t* d_out, uint64_t out_stride, uint32_t* d_out_len, uint32_t* d_status) {
+    if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len || !d_status))) return ZWZ_E_INVALID;
+    if (out_stride < ZWZ_CHUNK_SIZE) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status};
+    if (c->profiling) HIPCHK(hipEventRecord(c->ev_inf[0], c->stream));
+    HIPCHK(launch_inflate(a, c->stream));
+    if (c->profiling) {
+        HIPCHK(hipEventRecord(c->ev_inf[1], c->stream));
+        HIPCHK(hipEventSynchronize(c->ev_inf[1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_inf[0], c->ev_inf[1]));
+        c->stage_ms[kNumDeflateStages] += ms;
+    }
+    return ZWZ_OK;
+}
+
+// ---- host-buffer variants: pack chunks into 65536-byte slots of a pinned buffer, one H2D, run,
+// one D2H, unpack at the reference's 65535-byte stride.
+int zwz_deflate_batch(zwz_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n, uint8_t* out,
+                      uint32_t* out_len) {
+    if (!c || (n && (!in || !in_off || !in_len || !out || !out_len))) return ZWZ_E_INVALID;
+    for (uint32_t i = 0; i < n; i++) if (in_len[i] > ZWZ_CHUNK_SIZE) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t slice = c->max_batch;
+    for (uint32_t done = 0; done < n; done += slice) {
+        const uint32_t m = n - done < slice ? n - done : slice;
+        int rc = ensure_staging(c, m);
+        if (rc) return rc;
+        StageView v = stage_view(c, m);
+        for (uint32_t i = 0; i < m; i++) {
+            memcpy(v.h_in + (size_t)i * ZWZ_DEV_STRIDE, in + in_off[done + i], in_len[done + i]);
+            v.h_off[i] = (uint64_t)i * ZWZ_DEV_STRIDE;
+            v.h_len[i] = in_len[done + i];
+        }
+        HIPCHK(hipMemcpyAsync(v.d_in, v.h_in, (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(v.d_off, v.h_off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(v.d_len, v.h_len, m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        rc = zwz_deflate_batch_dev(c, v.d_in, v.d_off, v.d_len, m, v.d_out, ZWZ_DEV_STRIDE, v.d_olen);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(v.h_out, v.d_out, (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(v.h_olen, v.d_olen, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < m; i++) {
+            out_len[done + i] = v.h_olen[i];
+            memcpy(out + (size_t)(done + i) * ZWZ_CHUNK_SIZE, v.h_out + (size_t)i * ZWZ_DEV_STRIDE, v.h_olen[i]);
+        }
+    }
+    return ZWZ_OK;
+}
+
+int zwz_inflate_batch(zwz_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n, uint8_t* out,
+                      uint32_t* out_len, uint32_t* status) {
+    if (!c || (n && (!in || !in_off || !in_len || !out || !out_len || !status))) return ZWZ_E_INVALID;
+    for (uint32_t i = 0; i < n; i++) if (in_len[i] > ZWZ_CHUNK_SIZE) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t slice = c->max_batch;
+    for (uint32_t done = 0; done < n; done += slice) {
+        const uint32_t m = n - done < slice ? n - done : slice;
+        int rc = ensure_staging(c, m);
+        if (rc) return rc;
+        StageView v = stage_view(c, m);
+        for (uint32_t i = 0; i < m; i++) {
+            memcpy(v.h_in + (size_t)i * ZWZ_DEV_STRIDE, in + in_off[done + i], in_len[done + i]);
+            v.h_off[i] = (uint64_t)i * ZWZ_DEV_STRIDE;
+            v.h_len[i] = in_len[done + i];
+        }
+        HIPCHK(hipMemcpyAsync(v.d_in, v.h_in, (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(v.d_off, v.h_off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(v.d_len, v.h_len, m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        rc = zwz_inflate_batch_dev(c, v.d_in, v.d_off, v.d_len, m, v.d_out, ZWZ_DEV_STRIDE, v.d_olen, v.d_status);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(v.h_out, v.d_out, (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(v.h_olen, v.d_olen, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(v.h_status, v.d_status, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < m; i++) {
+            out_len[done + i] = v.h_olen[i];
+            status[done + i] = v.h_status[i];
+            memcpy(out + (size_t)(done + i) * ZWZ_CHUNK_SIZE, v.h_out + (size_t)i * ZWZ_DEV_STRIDE, v.h_olen[i]);
+        }
+    }
+    return ZWZ_OK;
+}
+
+}  // extern "C"
+
+namespace zwz {
+
+void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
+    uint8_t* p = static_cast<uint8_t*>(c->workspace);
+    const size_t n = c->max_batch;
+    auto take = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    a.entries = reinterpret_cast<uint2*>(take(n * kEntryStride * sizeof(uint2)));
+    a.links = reinterpret_cast<uint16_t*>(take(n * kLinkStride * sizeof(uint16_t)));
+    a.has128 = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
+    a.sym = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
+    a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
+    a.m32 = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
+    a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
+    a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
+    a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));
+}
+
+int ensure_staging(zwz_ctx* c, uint32_t m) {
+    if (m <= c->stage_chunks) return ZWZ_OK;
+    if (c->d_stage) { (void)hipFree(c->d_stage); c->d_stage = nullptr; }
+    if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
+    c->stage_chunks = 0;
+    const size_t bytes = stage_bytes(m);
+    hipError_t e = hipMalloc(&c->d_stage, bytes);
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(e, "staging allocation");
+    c->stage_chunks = m;
+    return ZWZ_OK;
+}
+
+}  // namespace zwz

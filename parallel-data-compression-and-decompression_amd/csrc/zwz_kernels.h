@@ -1,0 +1,66 @@
+// zwz_kernels.h -- HBM layout of the batch pipeline's intermediates and the launcher interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "huff_core.h"
+#include "zwz_common.h"
+
+namespace zwz {
+
+// Per-chunk strides of the intermediates (elements).  Everything is indexed [chunk][position].
+constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
+constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
+constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
+constexpr uint32_t kMatchThreads = 1024;
+constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
+constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
+constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes;   // 147136 of 163840
+constexpr uint32_t kBlockifyThreads = 256;
+constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
+constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
+constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + kMaskWords * 8 + kMaskWords * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);
+constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
+constexpr int kNumDeflateStages = 6;
+
+struct ChunkInfo { uint32_t n_sym, n_blocks; };
+
+struct BlockInfo {
+    uint16_t lfreq[kLCodes];
+    uint16_t dfreq[kDCodes];
+    uint32_t start, end;       // raw byte range covered
+    uint32_t flush_pos;        // zlib's strstart at the loop top before this block's flush
+    uint32_t first_sym;
+};
+
+struct BlockOut {
+    uint32_t type, hdr_bits, body_bits, eob_len, eob_code;
+    uint32_t hdr[kHdrWords];
+    uint16_t lcode[kLCodes + 2];
+    uint16_t dcode[kDCodes + 2];
+    uint8_t llen[kLCodes + 2];
+    uint8_t dlen[kDCodes + 2];
+};
+
+struct DeflateArgs {
+    const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned
+    uint8_t* out; uint64_t out_stride; uint32_t* out_len;                            // out_stride % 4 == 0, >= 65536
+    // workspace (sized for n chunks)
+    uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst; uint64_t* m32;
+    ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
+};
+
+struct InflateArgs {
+    const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;
+    uint8_t* out; uint64_t out_stride; uint32_t* out_len; uint32_t* status;
+};
+
+constexpr size_t kWorkspaceBytesPerChunk =
+    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 4 * (size_t)kMaskWords * 8 + sizeof(ChunkInfo) +
+    kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
+
+hipError_t configure_kernels();
+hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* stage_events);
+hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
+
+}  // namespace zwz

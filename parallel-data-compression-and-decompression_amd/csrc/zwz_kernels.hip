@@ -1,0 +1,561 @@
+// zwz_kernels.hip -- gfx950 kernels of the chunk codec (the reference's zlib call pair,
+// compression.cpp:119-134 and decompression.cpp:16-36, rebuilt as a batch pipeline over HBM).
+//
+// Compress, per batch of chunks (stage -> intermediate in HBM -> next stage):
+//   lz_links    one wave / chunk      15-bit hash + newest-first chain links (zlib's head/prev),
+//                                     64 positions per step, LDS head table, ballot de-duplication
+//   lz_match    one WG / 16 Ki tile   per-position best-of-32 / best-of-128 match records; the
+//                                     32 KiB history window (bytes + links) staged in LDS
+//   lz_parse    one lane / chunk      lazy-evaluation walk over the records -> symbol bit masks
+//   blockify    one WG / chunk        symbol ranks (popcount prefix), 16383-symbol block cuts,
+//                                     per-block histograms (LDS atomics)
+//   plan        one wave / block      zlib-exact Huffman trees, stored/static/dynamic choice, header
+//   encode      one WG / chunk        code lengths -> prefix scan -> bit offsets -> LDS bit packing,
+//                                     stored-block byte copy, Adler-32, 65535-byte truncation
+// Decompress:
+//   inflate     one wave / chunk      lane 0 decodes symbol batches, the wave moves the bytes
+//
+// All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "huff_core.h"
+#include "inflate_core.h"
+#include "lz_core.h"
+#include "zwz_kernels.h"
+
+namespace zwz {
+
+static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
+
+// ------------------------------------------------------------------------------------------------
+// lz_links: link[p] = newest position q < p with hash3(q) == hash3(p), 0 if none (zlib NIL).
+// One wave walks the chunk 64 positions at a time; the 64 KiB head table lives in LDS.
+__global__ __launch_bounds__(64) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                      const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    volatile uint16_t* head = reinterpret_cast<volatile uint16_t*>(smem);
+    const uint32_t chunk = blockIdx.x, lane = threadIdx.x;
+    const uint32_t L = in_len[chunk];
+    const uint8_t* data = in + in_off[chunk];
+    uint16_t* lk = links + (size_t)chunk * kLinkStride;
+
+    uint4* h4 = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = lane; i < 65536u / 16u; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t cur = lane < L ? data[lane] : 0u;
+    for (uint32_t base = 0; base < L; base += 64) {
+        const uint32_t p = base + lane;
+        uint32_t nxt = p + 64 < L ? data[p + 64] : 0u;
+        uint32_t n0 = __builtin_amdgcn_readlane(nxt, 0), n1 = __builtin_amdgcn_readlane(nxt, 1);
+        uint32_t b1 = __shfl_down(cur, 1), b2 = __shfl_down(cur, 2);
+        if (lane == 63) { b1 = n0; b2 = n1; }
+        if (lane == 62) b2 = n0;
+        const bool valid = p + kMinMatch <= L;
+        const uint32_t h = hash3(cur, b1, b2);
+        uint32_t prev = 0, rb = p;
+        if (valid) {
+            prev = head[h];
+            head[h] = (uint16_t)p;   // colliding lanes: one wins, fixed below
+            rb = head[h];
+        }
+        uint64_t dup = __ballot(valid && rb != p);
+        while (dup) {  // wave-uniform: one iteration per hash value shared inside this step
+            const uint32_t l = (uint32_t)__builtin_ctzll(dup);
+            const uint32_t hh = __builtin_amdgcn_readlane(h, l);
+            const uint64_t peers = __ballot(valid && h == hh);
+            if (valid && h == hh) {
+                const uint64_t lower = peers & lanes_below();
+                if (lower) prev = base + 63u - (uint32_t)__builtin_clzll(lower);
+                if ((peers >> lane) == 1ull) head[hh] = (uint16_t)p;  // newest peer owns the bucket
+            }
+            dup &= ~peers;
+        }
+        lk[p] = (uint16_t)(valid ? prev : 0u);
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lz_match: records for the positions of one 16 Ki tile.  LDS holds bytes [org, te+266) and links
+// [org, te) where org = tile start - 32506 (the furthest zlib may look back).
+__global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                 const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
+                                                                 uint2* __restrict__ entries, uint64_t* __restrict__ has128) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chunk = blockIdx.x / kTilesPerChunk, tile = blockIdx.x % kTilesPerChunk;
+    const uint32_t L = in_len[chunk];
+    const uint32_t ts = tile * kTile;
+    if (ts >= L && !(tile == 0)) return;
+    const uint32_t te = min(ts + kTile, L);
+    const uint32_t org = ts > kMaxDist ? (ts - kMaxDist) & ~3u : 0u;
+    const uint32_t data_end = min(L, te + kMaxMatch + 8u);            // bytes we may touch
+    const uint32_t data_words = (te + kMaxMatch + 8u - org + 3u) >> 2; // LDS extent (zero padded)
+    uint8_t* sdata = smem;
+    uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
+
+    const uint8_t* gdata = in + in_off[chunk];
+    const uint16_t* glink = links + (size_t)chunk * kLinkStride;
+    {   // stage the window; chunk base is 16-byte aligned (API contract) and org is a multiple of 4
+        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gdata + org);
+        uint32_t* s32 = reinterpret_cast<uint32_t*>(sdata);
+        const uint32_t full = data_end > org ? (data_end - org) >> 2 : 0u;
+        for (uint32_t i = threadIdx.x; i < data_words; i += kMatchThreads) {
+            uint32_t v = 0;
+            if (i < full) v = g32[i];
+            else {
+                uint32_t b = org + (i << 2);
+                for (uint32_t k = 0; k < 4; k++) if (b + k < data_end) v |= (uint32_t)gdata[b + k] << (8 * k);
+            }
+            s32[i] = v;
+        }
+        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(glink + org);
+        uint32_t* sl32 = reinterpret_cast<uint32_t*>(slink);
+        const uint32_t link_words = (te - org + 1u) >> 1;
+        for (uint32_t i = threadIdx.x; i < link_words; i += kMatchThreads) sl32[i] = l32[i];
+    }
+    __syncthreads();
+
+    uint2* ent = entries + (size_t)chunk * kEntryStride;
+    uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
+    const uint32_t tile_words_end = (te + 63u) & ~63u;
+    for (uint32_t p = ts + threadIdx.x; p < tile_words_end; p += kMatchThreads) {
+        uint32_t e128 = 0, e32 = 0;
+        if (p < te) lz_search(sdata, slink, org, p, L, e128, e32);
+        if (p < te) ent[p] = make_uint2(e128, e32);
+        const uint64_t m = __ballot(e128 != 0);
+        if (lane_id() == 0) hm[p >> 6] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lz_parse: the sequential lazy-match walk, one lane per chunk (many chunks in flight).
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n, const uint2* __restrict__ entries,
+                                                      const uint64_t* __restrict__ has128, uint64_t* __restrict__ sym,
+                                                      uint64_t* __restrict__ mst, uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info) {
+    const uint32_t chunk = blockIdx.x * 64 + threadIdx.x;
+    if (chunk >= n) return;
+    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    const uint32_t L = in_len[chunk];
+    ParseResult r = lz_parse([ent](uint32_t p, uint32_t sel) { uint2 e = ent[p]; return sel ? e.y : e.x; },
+                             has128 + (size_t)chunk * kMaskWords, L, sym + (size_t)chunk * kMaskWords,
+                             mst + (size_t)chunk * kMaskWords, m32 + (size_t)chunk * kMaskWords);
+    ChunkInfo ci;
+    ci.n_sym = r.n_sym;
+    const uint32_t s_in = (r.n_sym > 0 && !r.last_is_match) ? r.n_sym - 1 : r.n_sym;
+    ci.n_blocks = s_in / kSymsPerBlock + 1;
+    info[chunk] = ci;
+}
+
+// ------------------------------------------------------------------------------------------------
+// blockify: symbol ranks, block cuts every 16383 symbols, per-block histograms.
+static __device__ __forceinline__ uint32_t select_bit(uint64_t w, uint32_t k) {  // position of k-th (0-based) set bit
+    for (uint32_t i = 0; i < k; i++) w &= w - 1;
+    return (uint32_t)__builtin_ctzll(w);
+}
+
+__global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                   const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
+                                                                   const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
+                                                                   const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
+                                                                   BlockInfo* __restrict__ blocks) {
+    __shared__ uint64_t s_sym[kMaskWords];
+    __shared__ uint32_t s_rank[kMaskWords + 1];   // symbols before word w
+    __shared__ uint32_t s_hist[kMaxBlocks][kLCodes + kDCodes + 4];
+    __shared__ uint32_t s_wsum[kBlockifyThreads / 64];
+    __shared__ uint32_t s_start[kMaxBlocks + 1], s_flush[kMaxBlocks];
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
+    const uint32_t L = in_len[chunk];
+    const uint32_t nwords = (L + 63) >> 6;
+    const ChunkInfo ci = info[chunk];
+    const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
+    const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
+    const uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
+
+    for (uint32_t i = tid; i < kMaxBlocks * (kLCodes + kDCodes + 4); i += kBlockifyThreads) (&s_hist[0][0])[i] = 0;
+    if (tid <= kMaxBlocks) s_start[tid] = L;
+    if (tid < kMaxBlocks) s_flush[tid] = L;
+    // popcount prefix over the 1024 mask words: 4 words per thread
+    constexpr uint32_t kPer = kMaskWords / kBlockifyThreads;
+    uint64_t w[kPer]; uint32_t c[kPer], tsum = 0;
+    for (uint32_t k = 0; k < kPer; k++) {
+        uint32_t wi = tid * kPer + k;
+        w[k] = wi < nwords ? gsym[wi] : 0ull;
+        s_sym[wi] = w[k];
+        c[k] = (uint32_t)__popcll(w[k]); tsum += c[k];
+    }
+    uint32_t incl = tsum;
+    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d); if (lane_id() >= d) incl += v; }
+    if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t i = 0; i < (tid >> 6); i++) wbase += s_wsum[i];
+    uint32_t run = wbase + incl - tsum;
+    for (uint32_t k = 0; k < kPer; k++) { s_rank[tid * kPer + k] = run; run += c[k]; }
+    if (tid == kBlockifyThreads - 1) s_rank[kMaskWords] = run;
+    __syncthreads();
+
+    // block cuts: symbol #16383*b starts block b; the flush of block b-1 follows the loop-top
+    // after its last symbol's start position
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t wi = tid * kPer + k, r0 = s_rank[wi], r1 = r0 + c[k];
+        for (uint32_t b = 1; b < ci.n_blocks; b++) {
+            const uint32_t first = b * kSymsPerBlock, lastprev = first - 1;
+            if (first >= r0 && first < r1) s_start[b] = (wi << 6) + select_bit(w[k], first - r0);
+            if (lastprev >= r0 && lastprev < r1) s_flush[b - 1] = (wi << 6) + select_bit(w[k], lastprev - r0) + 1;
+        }
+    }
+    if (tid == 0) s_start[0] = 0;
+    __syncthreads();
+
+    // histograms, position-parallel (coalesced byte / record reads)
+    const uint8_t* data = in + in_off[chunk];
+    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    for (uint32_t p = tid; p < (nwords << 6); p += kBlockifyThreads) {
+        const uint32_t wi = p >> 6, bit = p & 63;
+        const uint64_t sw = s_sym[wi];
+        if (!((sw >> bit) & 1ull)) continue;
+        const uint32_t idx = s_rank[wi] + (uint32_t)__popcll(sw & ((1ull << bit) - 1ull));
+        uint32_t b = idx / kSymsPerBlock;
+        if (b >= ci.n_blocks) b = ci.n_blocks - 1;
+        if ((gmst[wi] >> bit) & 1ull) {
+            const uint2 e2 = ent[p];
+            const uint32_t e = ((gm32[wi] >> bit) & 1ull) ? e2.y : e2.x;
+            atomicAdd(&s_hist[b][257u + length_code(entry_len(e) - kMinMatch)], 1u);
+            atomicAdd(&s_hist[b][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
+        } else {
+            atomicAdd(&s_hist[b][data[p]], 1u);
+        }
+    }
+    __syncthreads();
+    BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks;
+    for (uint32_t b = 0; b < ci.n_blocks; b++) {
+        for (uint32_t i = tid; i < kLCodes; i += kBlockifyThreads) bi[b].lfreq[i] = (uint16_t)(i == 256 ? 1u : s_hist[b][i]);
+        if (tid < kDCodes) bi[b].dfreq[tid] = (uint16_t)s_hist[b][kLCodes + tid];
+        if (tid == 0) {
+            bi[b].start = s_start[b]; bi[b].end = b + 1 < ci.n_blocks ? s_start[b + 1] : L;
+            bi[b].flush_pos = b + 1 < ci.n_blocks ? s_flush[b] : L;
+            bi[b].first_sym = b * kSymsPerBlock;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan: one wave per (chunk, block); lane 0 runs zlib's tree construction with its scratch in LDS.
+__global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
+                                                  BlockOut* __restrict__ plans) {
+    __shared__ TreeScratch ts;
+    __shared__ BlockCodes bc;
+    __shared__ uint32_t hdr[kHdrWords];
+    __shared__ uint16_t lf[kLCodes], df[kDCodes];
+    const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
+    if (b >= info[chunk].n_blocks) return;
+    const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
+    BlockOut* bo = plans + (size_t)chunk * kMaxBlocks + b;
+    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
+    if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) hdr[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t last = b + 1 == info[chunk].n_blocks;
+        const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
+        BlockPlan bp = plan_block(ts, lf, df, bi->end - bi->start, stored_ok, last, bc, hdr);
+        bo->type = bp.type; bo->hdr_bits = bp.hdr_bits; bo->body_bits = bp.body_bits;
+        bo->eob_len = bc.llen[256]; bo->eob_code = bc.lcode[256];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) { bo->llen[i] = bc.llen[i]; bo->lcode[i] = bc.lcode[i]; }
+    if (threadIdx.x < kDCodes) { bo->dlen[threadIdx.x] = bc.dlen[threadIdx.x]; bo->dcode[threadIdx.x] = bc.dcode[threadIdx.x]; }
+    for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) bo->hdr[i] = hdr[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode: bit-pack one chunk's zlib stream into LDS, then stream the first <= 65535 bytes out.
+struct EncBlock { uint32_t type, hdr_pos, body_pos, body_bits, start, end, first_sym, eob_len, eob_code, sym_bits_before, data_byte; };
+
+static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpos, uint64_t v, uint32_t n) {
+    // OR n (<= 48) bits of v at absolute bit position; anything at or past word kOutWords is dropped
+    if (n == 0) return;
+    const uint32_t w = (uint32_t)(bitpos >> 5), o = (uint32_t)(bitpos & 31u);
+    const uint64_t lo = v << o;
+    const uint32_t hi = o ? (uint32_t)(v >> (64u - o)) : 0u;
+    if (w < kOutWords && (uint32_t)lo) atomicOr(&out[w], (uint32_t)lo);
+    if (w + 1 < kOutWords && (uint32_t)(lo >> 32)) atomicOr(&out[w + 1], (uint32_t)(lo >> 32));
+    if (w + 2 < kOutWords && hi) atomicOr(&out[w + 2], hi);
+}
+
+__global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
+                                                                const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
+                                                                const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
+                                                                const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
+                                                                uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
+    uint64_t* s_sym = reinterpret_cast<uint64_t*>(smem + kOutWords * 4);          // kMaskWords
+    uint32_t* s_rank = reinterpret_cast<uint32_t*>(s_sym + kMaskWords);           // kMaskWords
+    uint16_t* s_lcode = reinterpret_cast<uint16_t*>(s_rank + kMaskWords);         // kMaxBlocks * 288
+    uint16_t* s_dcode = s_lcode + kMaxBlocks * 288;                               // kMaxBlocks * 32
+    uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
+    uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
+    __shared__ EncBlock s_blk[kMaxBlocks];
+    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_wsum2[kEncodeThreads / 64];
+    __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
+    __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
+
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
+    const uint32_t L = in_len[chunk];
+    const uint32_t nwords = (L + 63) >> 6;
+    const ChunkInfo ci = info[chunk];
+    const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks;
+    const BlockOut* bo = plans + (size_t)chunk * kMaxBlocks;
+    const uint8_t* data = in + in_off[chunk];
+    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
+    const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
+    const uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
+
+    for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
+    // symbol ranks again (cheaper to recompute than to round-trip through HBM)
+    {
+        uint64_t w = tid < nwords ? gsym[tid] : 0ull;   // kEncodeThreads == kMaskWords
+        s_sym[tid] = w;
+        uint32_t cnt = (uint32_t)__popcll(w), incl = cnt;
+        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d); if (lane_id() >= d) incl += v; }
+        if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t i = 0; i < (tid >> 6); i++) wbase += s_wsum[i];
+        s_rank[tid] = wbase + incl - cnt;
+    }
+    for (uint32_t b = 0; b < ci.n_blocks; b++) {
+        for (uint32_t i = tid; i < kLCodes; i += kEncodeThreads) { s_lcode[b * 288 + i] = bo[b].lcode[i]; s_llen[b * 288 + i] = bo[b].llen[i]; }
+        if (tid < kDCodes) { s_dcode[b * 32 + tid] = bo[b].dcode[tid]; s_dlen[b * 32 + tid] = bo[b].dlen[tid]; }
+    }
+    if (tid == 0) {
+        // stream layout: 2 header bytes, blocks bit-contiguous (stored blocks and the final block pad to a byte)
+        uint64_t bit = 16; uint32_t before = 0;
+        for (uint32_t b = 0; b < ci.n_blocks; b++) {
+            EncBlock e;
+            e.type = bo[b].type; e.hdr_pos = (uint32_t)bit; e.start = bi[b].start; e.end = bi[b].end;
+            e.first_sym = bi[b].first_sym; e.eob_len = bo[b].eob_len; e.eob_code = bo[b].eob_code;
+            e.body_bits = bo[b].body_bits; e.sym_bits_before = before; e.data_byte = 0;
+            bit += bo[b].hdr_bits;
+            if (e.type == kStored) {
+                bit = (bit + 7) & ~7ull;
+                e.body_pos = (uint32_t)bit;          // LEN/NLEN start
+                e.data_byte = (uint32_t)(bit >> 3) + 4;
+                bit += 32 + 8ull * (e.end - e.start);
+            } else {
+                e.body_pos = (uint32_t)bit;
+                bit += e.body_bits;
+                before += e.body_bits - e.eob_len;
+            }
+            if (b + 1 == ci.n_blocks) bit = (bit + 7) & ~7ull;
+            s_blk[b] = e;
+        }
+        s_total_bytes = (uint32_t)(bit >> 3) + 4;    // + Adler-32
+    }
+    __syncthreads();
+
+    if (tid == 0) lds_or_bits(s_out, 0, 0x9c78u, 16);
+    for (uint32_t b = 0; b < ci.n_blocks; b++) {
+        const EncBlock e = s_blk[b];
+        const uint32_t hw = (bo[b].hdr_bits + 31) >> 5;
+        if (tid < hw) {
+            uint32_t nb = bo[b].hdr_bits - (tid << 5); if (nb > 32) nb = 32;
+            uint32_t v = bo[b].hdr[tid]; if (nb < 32) v &= (1u << nb) - 1u;
+            lds_or_bits(s_out, (uint64_t)e.hdr_pos + (tid << 5), v, nb);
+        }
+        if (tid == 0) {
+            if (e.type == kStored) {
+                const uint32_t len = e.end - e.start;
+                lds_or_bits(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
+            } else {
+                lds_or_bits(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
+            }
+        }
+    }
+
+    // symbols: one position per thread per step; exclusive scan of code lengths gives bit offsets
+    uint32_t carry = 0;        // symbol bits emitted before this step (all Huffman blocks)
+    uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
+    uint8_t* s_out8 = reinterpret_cast<uint8_t*>(s_out);
+    for (uint32_t base = 0; base < (nwords << 6); base += kEncodeThreads) {
+        const uint32_t p = base + tid, wi = p >> 6, bit = p & 63;
+        uint64_t v = 0; uint32_t nb = 0, blk = 0;
+        bool is_sym = false;
+        uint32_t byte = 0;
+        if (p < L) {
+            byte = data[p];
+            a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
+            const uint64_t sw = s_sym[wi];
+            is_sym = (sw >> bit) & 1ull;
+            const uint32_t idx = s_rank[wi] + (uint32_t)__popcll(sw & ((1ull << bit) - 1ull));
+            blk = idx / kSymsPerBlock; if (blk >= ci.n_blocks) blk = ci.n_blocks - 1;
+            // a covered position belongs to the block of the symbol that covers it: rank counts
+            // symbols starting before p, so idx-1 is that symbol
+            if (!is_sym) { blk = (idx - 1) / kSymsPerBlock; if (blk >= ci.n_blocks) blk = ci.n_blocks - 1; }
+            if (s_blk[blk].type == kStored) {
+                const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
+                if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
+            } else if (is_sym) {
+                uint32_t e = 0;
+                if ((gmst[wi] >> bit) & 1ull) { const uint2 e2 = ent[p]; e = ((gm32[wi] >> bit) & 1ull) ? e2.y : e2.x; }
+                symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, e, byte, v, nb);
+            }
+        }
+        uint32_t incl = nb;
+        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane_id() >= d) incl += t; }
+        uint32_t* ws = (base / kEncodeThreads) & 1 ? s_wsum2 : s_wsum;   // double buffer: one barrier per step
+        if (lane_id() == 63) ws[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { uint32_t s = ws[i]; if (i < (tid >> 6)) wbase += s; total += s; }
+        if (nb) {
+            const uint32_t before = carry + wbase + incl - nb;   // symbol bits before this symbol
+            const EncBlock& e = s_blk[blk];
+            lds_or_bits(s_out, (uint64_t)e.body_pos + (before - e.sym_bits_before), v, nb);
+        }
+        carry += total;
+    }
+
+    // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
+    for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
+    if (lane_id() == 0) { s_adler_a[tid >> 6] = a_sum; s_adler_b[tid >> 6] = b_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long a = 1, b = L;
+        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_adler_a[i]; b += s_adler_b[i]; }
+        const uint32_t ad = (uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull);
+        const uint32_t be = __builtin_bswap32(ad);
+        lds_or_bits(s_out, 8ull * (s_total_bytes - 4), be, 32);
+        out_len[chunk] = s_total_bytes < kChunk ? s_total_bytes : kChunk;
+    }
+    __syncthreads();
+    const uint32_t n_out = s_total_bytes < kChunk ? s_total_bytes : kChunk;
+    uint32_t* gout = reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride);
+    for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// inflate: one wave per chunk.  Lane 0 owns the bit reader and the tables; the wave moves bytes.
+struct InflateWaveMem {
+    InflateTables t;
+    uint8_t lens[320];
+    uint32_t batch[kBatch], pos[kBatch];
+};
+
+__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                  const uint32_t* __restrict__ in_len, uint32_t n,
+                                                                  uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
+    __shared__ InflateWaveMem s_mem[kInflateThreads / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t chunk = blockIdx.x * (kInflateThreads / 64) + wave;
+    if (chunk >= n) return;
+    InflateWaveMem& m = s_mem[wave];
+    const uint8_t* src = in + in_off[chunk];
+    uint8_t* dst = out + (size_t)chunk * out_stride;
+    const uint32_t nin = in_len[chunk];
+
+    InflateState st;
+    uint32_t go = 0;
+    if (lane == 0) go = inflate_begin(st, src, nin) ? 1u : 0u;
+    go = __builtin_amdgcn_readfirstlane(go);
+    uint32_t fenced = 0;      // every output byte below this offset is visible to the whole wave
+    while (go) {
+        uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
+        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, m.lens, soff, slen); }
+        kind = __builtin_amdgcn_readfirstlane(kind);
+        if (kind == kBlkStop) break;
+        if (kind == kBlkStored) {
+            soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen);
+            opos = __builtin_amdgcn_readfirstlane(opos);
+            uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
+            for (uint32_t i = lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
+            uint32_t stop = 0;
+            if (lane == 0) {
+                st.out_pos += cp;
+                if (cp < slen) st.status = kInfOverflow;
+                stop = st.status != kInfRunning;
+            }
+            if (__builtin_amdgcn_readfirstlane(stop)) break;
+        } else {
+            uint32_t done = 0;
+            while (!done) {
+                uint32_t k = 0;
+                if (lane == 0) { bool d; k = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d); done = d; }
+                k = __builtin_amdgcn_readfirstlane(k); done = __builtin_amdgcn_readfirstlane(done);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // lane 0's LDS batch -> all lanes
+                const uint32_t sv = lane < k ? m.batch[lane] : 0u, sp = lane < k ? m.pos[lane] : 0u;
+                if (lane < k && sv < 256u) dst[sp] = (uint8_t)sv;
+                uint64_t matches = __ballot(lane < k && sv >= 256u);
+                while (matches) {   // in order: a match may read what an earlier symbol of this batch wrote
+                    const uint32_t l = (uint32_t)__builtin_ctzll(matches);
+                    matches &= matches - 1;
+                    const uint32_t mv = __builtin_amdgcn_readlane(sv, l), mp = __builtin_amdgcn_readlane(sp, l);
+                    const uint32_t len = mv >> 16, dist = mv & 0xffffu;
+                    const uint32_t from = mp - dist, span = len < dist ? len : dist;
+                    if (from + span > fenced) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_s_waitcnt(0);
+                        fenced = mp;
+                    }
+                    for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = dst[from + (i % dist)];
+                }
+            }
+            uint32_t stop = 0;
+            if (lane == 0) stop = st.status != kInfRunning;
+            if (__builtin_amdgcn_readfirstlane(stop)) break;
+        }
+        uint32_t fin = 0;
+        if (lane == 0 && st.last) { st.status = kInfEnd; fin = 1; }
+        if (__builtin_amdgcn_readfirstlane(fin)) break;
+    }
+    if (lane == 0) { out_len[chunk] = st.out_pos; status[chunk] = st.status; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+#define ZWZ_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t configure_kernels() {
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
+    return hipSuccess;
+}
+
+hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
+    if (a.n == 0) return hipSuccess;
+    if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), 65536, s, a.in, a.in_off, a.in_len, a.links);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(lz_match_kernel, dim3(a.n * kTilesPerChunk), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
+                       a.links, a.entries, a.has128);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
+    hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst, a.m32,
+                       a.info, a.blocks);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
+    hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.plans);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
+    hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
+                       a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len);
+    if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
+    return hipGetLastError();
+}
+
+hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    const uint32_t per = kInflateThreads / 64;
+    hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
+                       a.out_stride, a.out_len, a.status);
+    return hipGetLastError();
+}
+
+}  // namespace zwz

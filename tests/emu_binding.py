@@ -18,6 +18,9 @@ def load():
     lib.emu_chunk_stream.restype = ctypes.c_uint32
     lib.emu_chunk_stream.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
                                      ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_inflate.restype = ctypes.c_uint32
+    lib.emu_inflate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
+                                ctypes.POINTER(ctypes.c_uint32)]
     return lib
 
 
@@ -27,3 +30,10 @@ def chunk_stream(lib, data: bytes) -> bytes:
     n = lib.emu_chunk_stream(data, len(data), out, cap, None, None)
     assert n != 0xFFFFFFFF, "block plan mispredicted the body size"
     return out.raw[:n]
+
+
+def inflate(lib, payload: bytes, cap: int = 65535):
+    out = ctypes.create_string_buffer(cap + 8)
+    st = ctypes.c_uint32()
+    n = lib.emu_inflate(payload, len(payload), out, cap, ctypes.byref(st))
+    return out.raw[:n], st.value
