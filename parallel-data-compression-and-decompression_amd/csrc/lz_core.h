@@ -26,10 +26,10 @@ ZWZ_HD uint32_t load_u32(const uint8_t* base, uint32_t off) {
 #endif
 }
 
-// Common prefix length of data[a..] and data[b..], capped at max_len.  `data` is indexed
-// relative to `org` (window origin, multiple of 4); reads up to 7 bytes past max_len.
-ZWZ_HD uint32_t match_len(const uint8_t* data, uint32_t a, uint32_t b, uint32_t max_len) {
-    uint32_t k = 0;
+// Common prefix length of data[a..] and data[b..] given the first k0 bytes are known equal,
+// capped at max_len.  Reads up to 7 bytes past a + max_len / b + max_len.
+ZWZ_HD uint32_t match_len_from(const uint8_t* data, uint32_t a, uint32_t b, uint32_t k0, uint32_t max_len) {
+    uint32_t k = k0;
     while (k < max_len) {
         uint32_t x = load_u32(data, a + k) ^ load_u32(data, b + k);
         if (x) {
@@ -43,6 +43,10 @@ ZWZ_HD uint32_t match_len(const uint8_t* data, uint32_t a, uint32_t b, uint32_t 
 
 // Match records of position p.  data/link are window views: data[i - org], link[i - org] hold
 // byte i / chain predecessor of position i (0 = NIL).  L = chunk length.
+//
+// Candidate filter (same accept/reject decisions as zlib's longest_match, fewer loads): a
+// candidate can only beat `best` if it agrees with the scan at offset `best`; while best is still
+// 2 that is the 3-byte prefix itself, tested on one cached word.
 ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
                       uint32_t& e128, uint32_t& e32) {
     e128 = 0; e32 = 0;
@@ -54,20 +58,29 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     const uint32_t max_len = lookahead < kMaxMatch ? lookahead : kMaxMatch;
     const uint32_t nice = lookahead < kNiceLen ? lookahead : kNiceLen;
     const uint32_t limit = p > kMaxDist ? p - kMaxDist : 0;
+    const uint32_t pp = p - org;
+    const uint32_t head4 = load_u32(data, pp);           // scan[0..3]
     uint32_t best = kMinMatch - 1, best_pos = 0, n = 0;
+    uint32_t scan_at_best = 0;                           // scan[best], valid once best >= 3
     bool have32 = false;
     for (;;) {
-        // zlib's quick reject: a longer match must also agree at offset `best`
-        if (data[cur - org + best] == data[p - org + best]) {
-            uint32_t len = match_len(data, cur - org, p - org, max_len);
-            if (len > best) {
-                best = len; best_pos = cur;
-                if (len >= nice) break;
-            }
+        const uint32_t c = cur - org;
+        uint32_t len = 0;
+        if (best < kMinMatch) {
+            const uint32_t x = load_u32(data, c) ^ head4;
+            if ((x & 0xffffffu) == 0) len = x ? 3u : match_len_from(data, c, pp, 4u, max_len);
+        } else if (data[c + best] == scan_at_best) {
+            len = match_len_from(data, c, pp, 0u, max_len);
+        }
+        if (len > max_len) len = max_len;
+        if (len > best) {
+            best = len; best_pos = cur;
+            if (len >= nice) break;
+            scan_at_best = data[pp + best];
         }
         n++;
         if (n == kShortChain) { have32 = true; e32 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0; }
-        cur = link[cur - org];
+        cur = link[c];
         if (cur <= limit || n == kMaxChain) break;
     }
     e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0;

@@ -30,52 +30,98 @@ static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_
 
 // ------------------------------------------------------------------------------------------------
 // lz_links: link[p] = newest position q < p with hash3(q) == hash3(p), 0 if none (zlib NIL).
-// One wave walks the chunk 64 positions at a time; the 64 KiB head table lives in LDS.
+// One wave walks the chunk 64 positions at a time; the 64 KiB head table lives in LDS, next to a
+// 4 KiB ring of input bytes that is refilled 2 KiB at a time, one refill ahead (the global loads
+// of a refill are issued 32 steps before they are needed, so no step waits on HBM).
+// A step's critical path is one LDS round trip: head read -> write -> read-back (collision check).
+constexpr uint32_t kLinksHalf = 2048, kLinksRing = 2 * kLinksHalf;
+
 __global__ __launch_bounds__(64) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                       const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    volatile uint16_t* head = reinterpret_cast<volatile uint16_t*>(smem);
+    // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
+    // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
+    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries
+    uint8_t* ring = reinterpret_cast<uint8_t*>(head + 32768);                // kLinksRing + 16 mirror bytes
     const uint32_t chunk = blockIdx.x, lane = threadIdx.x;
     const uint32_t L = in_len[chunk];
-    const uint8_t* data = in + in_off[chunk];
+    const uint8_t* data = in + in_off[chunk];                                // 16-byte aligned (API contract)
     uint16_t* lk = links + (size_t)chunk * kLinkStride;
 
-    uint4* h4 = reinterpret_cast<uint4*>(smem);
+    uint4* h4 = reinterpret_cast<uint4*>(head);
     for (uint32_t i = lane; i < 65536u / 16u; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+
+    // half h of the input = bytes [2048 h, 2048 h + 2048): 32 bytes per lane as two uint4
+    const uint32_t n_half = (L + kLinksHalf - 1) / kLinksHalf;
+    auto fetch_half = [&](uint32_t h, uint4& a, uint4& b) {
+        const uint32_t o = h * kLinksHalf + lane * 32u;
+        a = make_uint4(0, 0, 0, 0); b = a;
+        // whole 16-byte vectors up to the chunk length rounded up to 16 (API contract: the slot is
+        // readable that far; bytes past L never reach a valid hash)
+        const uint32_t R = (L + 15u) & ~15u;
+        const uint4* g = reinterpret_cast<const uint4*>(data + o);
+        if (o + 16u <= R) a = g[0];
+        if (o + 32u <= R) b = g[1];
+    };
+    auto store_half = [&](uint32_t h, const uint4& a, const uint4& b) {
+        uint4* r = reinterpret_cast<uint4*>(ring + (h & 1u) * kLinksHalf + lane * 32u);
+        r[0] = a; r[1] = b;
+        if ((h & 1u) == 0 && lane == 0) *reinterpret_cast<uint4*>(ring + kLinksRing) = a;   // wrap-around mirror
+    };
+    uint4 pa, pb;
+    fetch_half(0, pa, pb);
+    store_half(0, pa, pb);
+    fetch_half(1, pa, pb);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t cur = lane < L ? data[lane] : 0u;
-    for (uint32_t base = 0; base < L; base += 64) {
-        const uint32_t p = base + lane;
-        uint32_t nxt = p + 64 < L ? data[p + 64] : 0u;
-        uint32_t n0 = __builtin_amdgcn_readlane(nxt, 0), n1 = __builtin_amdgcn_readlane(nxt, 1);
-        uint32_t b1 = __shfl_down(cur, 1), b2 = __shfl_down(cur, 2);
-        if (lane == 63) { b1 = n0; b2 = n1; }
-        if (lane == 62) b2 = n0;
-        const bool valid = p + kMinMatch <= L;
-        const uint32_t h = hash3(cur, b1, b2);
-        uint32_t prev = 0, rb = p;
-        if (valid) {
-            prev = head[h];
-            head[h] = (uint16_t)p;   // colliding lanes: one wins, fixed below
-            rb = head[h];
-        }
-        uint64_t dup = __ballot(valid && rb != p);
-        while (dup) {  // wave-uniform: one iteration per hash value shared inside this step
-            const uint32_t l = (uint32_t)__builtin_ctzll(dup);
-            const uint32_t hh = __builtin_amdgcn_readlane(h, l);
-            const uint64_t peers = __ballot(valid && h == hh);
-            if (valid && h == hh) {
-                const uint64_t lower = peers & lanes_below();
-                if (lower) prev = base + 63u - (uint32_t)__builtin_clzll(lower);
-                if ((peers >> lane) == 1ull) head[hh] = (uint16_t)p;  // newest peer owns the bucket
+    uint32_t w_cur = load_u32(ring, lane);           // bytes p..p+3 of this step
+    for (uint32_t h = 0; h < n_half; h++) {
+        // ring holds half h; registers hold half h+1: publish it, then start loading half h+2
+        store_half(h + 1, pa, pb);
+        fetch_half(h + 2, pa, pb);
+        const uint32_t end = min(L, (h + 1) * kLinksHalf);
+        for (uint32_t base = h * kLinksHalf; base < end; base += 64) {
+            const uint32_t p = base + lane;
+            const uint32_t w_next = load_u32(ring, (p + 64u) & (kLinksRing - 1u));   // next step's bytes, off the critical path
+            const bool valid = p + kMinMatch <= L;
+            const uint32_t hsh = hash3(w_cur & 0xffu, (w_cur >> 8) & 0xffu, (w_cur >> 16) & 0xffu);
+            uint32_t prev = 0, rb = p;
+            if (valid) {
+                prev = head[hsh];
+                head[hsh] = (uint16_t)p;          // colliding lanes: one wins, fixed below
+                asm volatile("" ::: "memory");    // the read-back must see other lanes' stores: no forwarding
+                rb = head[hsh];
             }
-            dup &= ~peers;
+            uint64_t dup = __ballot(valid && rb != p);
+            while (dup) {  // wave-uniform: one iteration per hash value shared inside this step
+                const uint32_t l = (uint32_t)__builtin_ctzll(dup);
+                const uint32_t hh = __builtin_amdgcn_readlane(hsh, l);
+                const uint64_t peers = __ballot(valid && hsh == hh);
+                if (valid && hsh == hh) {
+                    const uint64_t lower = peers & lanes_below();
+                    if (lower) prev = base + 63u - (uint32_t)__builtin_clzll(lower);
+                    if ((peers >> lane) == 1ull) head[hh] = (uint16_t)p;  // newest peer owns the bucket
+                }
+                dup &= ~peers;
+            }
+            lk[p] = (uint16_t)(valid ? prev : 0u);
+            w_cur = w_next;
         }
-        lk[p] = (uint16_t)(valid ? prev : 0u);
-        cur = nxt;
     }
+}
+
+// Workgroup copy of n 16-byte vectors global -> LDS with eight loads in flight per thread.
+static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, uint32_t n) {
+    const uint32_t T = blockDim.x;
+    uint32_t i = threadIdx.x;
+    for (; i + 7 * T < n; i += 8 * T) {
+        uint4 r[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) r[u] = src[i + u * T];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) dst[i + u * T] = r[u];
+    }
+    for (; i < n; i += T) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -90,7 +136,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     const uint32_t ts = tile * kTile;
     if (ts >= L && !(tile == 0)) return;
     const uint32_t te = min(ts + kTile, L);
-    const uint32_t org = ts > kMaxDist ? (ts - kMaxDist) & ~3u : 0u;
+    const uint32_t org = ts > kMaxDist ? (ts - kMaxDist) & ~7u : 0u;
     const uint32_t data_end = min(L, te + kMaxMatch + 8u);            // bytes we may touch
     const uint32_t data_words = (te + kMaxMatch + 8u - org + 3u) >> 2; // LDS extent (zero padded)
     uint8_t* sdata = smem;
@@ -98,23 +144,24 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 
     const uint8_t* gdata = in + in_off[chunk];
     const uint16_t* glink = links + (size_t)chunk * kLinkStride;
-    {   // stage the window; chunk base is 16-byte aligned (API contract) and org is a multiple of 4
-        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gdata + org);
+    {   // stage the window with 16-byte loads, eight in flight per thread before the first LDS
+        // store (one load per loop trip would leave each wave waiting out a full HBM round trip).
+        // Chunk base is 16-byte aligned (API contract); org is a multiple of 8.
+        const uint32_t data_bytes = data_end > org ? data_end - org : 0u;
+        const uint32_t nvec = data_bytes >> 4;
+        const uint4* g4 = reinterpret_cast<const uint4*>(gdata + org);
+        uint4* s4 = reinterpret_cast<uint4*>(sdata);
+        copy_vec16(s4, g4, nvec);
         uint32_t* s32 = reinterpret_cast<uint32_t*>(sdata);
-        const uint32_t full = data_end > org ? (data_end - org) >> 2 : 0u;
-        for (uint32_t i = threadIdx.x; i < data_words; i += kMatchThreads) {
-            uint32_t v = 0;
-            if (i < full) v = g32[i];
-            else {
-                uint32_t b = org + (i << 2);
-                for (uint32_t k = 0; k < 4; k++) if (b + k < data_end) v |= (uint32_t)gdata[b + k] << (8 * k);
-            }
+        for (uint32_t i = (nvec << 2) + threadIdx.x; i < data_words; i += kMatchThreads) {   // ragged tail + zero pad
+            uint32_t v = 0, b = org + (i << 2);
+            for (uint32_t k = 0; k < 4; k++) if (b + k < data_end) v |= (uint32_t)gdata[b + k] << (8 * k);
             s32[i] = v;
         }
-        const uint32_t* l32 = reinterpret_cast<const uint32_t*>(glink + org);
-        uint32_t* sl32 = reinterpret_cast<uint32_t*>(slink);
-        const uint32_t link_words = (te - org + 1u) >> 1;
-        for (uint32_t i = threadIdx.x; i < link_words; i += kMatchThreads) sl32[i] = l32[i];
+        const uint32_t lvec = (te - org + 7u) >> 3;   // 8 links per 16 bytes; the row has 65536 entries
+        const uint4* l4 = reinterpret_cast<const uint4*>(glink + org);
+        uint4* sl4 = reinterpret_cast<uint4*>(slink);
+        copy_vec16(sl4, l4, lvec);
     }
     __syncthreads();
 
@@ -523,7 +570,7 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
 #define ZWZ_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t configure_kernels() {
-    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
     return hipSuccess;
@@ -532,7 +579,7 @@ hipError_t configure_kernels() {
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), 65536, s, a.in, a.in_off, a.in_len, a.links);
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n * kTilesPerChunk), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128);
