@@ -75,9 +75,11 @@ void *zwz_ctx_stream(zwz_ctx *ctx);             /* the context's hipStream_t */
 int zwz_ctx_sync(zwz_ctx *ctx);
 
 /* ---- device-resident batches (asynchronous on the context's stream) ------------------------
- * d_in + d_in_off[i] is chunk i (d_in_len[i] <= 65535 bytes, d_in_off[i] % 16 == 0 for deflate).
- * Chunk i's result goes to d_out + i * out_stride (out_stride % 16 == 0, >= 65536) with its
- * length in d_out_len[i].  All pointers are device memory on the context's GPU. */
+ * d_in + d_in_off[i] is chunk i: d_in_len[i] <= 65535 bytes, d_in and every d_in_off[i] multiples
+ * of 16, and the slot readable up to its length rounded up to 16 (the kernels stream whole 16-byte
+ * vectors; the extra bytes never influence a result).  Chunk i's result goes to
+ * d_out + i * out_stride (out_stride % 16 == 0, >= 65536) with its length in d_out_len[i].
+ * All pointers are device memory on the context's GPU. */
 int zwz_deflate_batch_dev(zwz_ctx *ctx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                           uint32_t n, uint8_t *d_out, uint64_t out_stride, uint32_t *d_out_len);
 int zwz_inflate_batch_dev(zwz_ctx *ctx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,

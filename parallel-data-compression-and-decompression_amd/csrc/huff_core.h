@@ -250,6 +250,60 @@ ZWZ_HD BlockPlan plan_block(TreeScratch& ts, const uint16_t* lfreq, const uint16
     return bp;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stored-block shortcut.  zlib stores a block iff stored_len + 4 <= min(opt_lenb, static_lenb).
+// static_len is a plain weighted sum; opt_len needs zlib's exact trees -- unless a LOWER bound on
+// it already clears the threshold.  Every prefix code costs at least the optimal Huffman cost
+// (tie-break independent: the sum of the internal node weights), so
+//     opt_len >= huff(lit) + huff(dist) + extra bits + 14 + 3*4 + ceil(used_codes / 6)
+// (at least 4 code-length-code lengths are sent; one code-length symbol of >= 1 bit describes at
+// most 6 non-zero lengths).  Incompressible data clears the threshold by ~100 bits per block, so
+// the heap-built trees are only constructed for blocks that may really be Huffman coded.
+
+// Optimal prefix-code cost of ascending weights sorted[0..m) (two-queue merge).  queue: m words.
+ZWZ_HD uint32_t huffman_cost_sorted(const uint16_t* sorted, uint32_t m, uint32_t* queue) {
+    if (m < 2) return 0;
+    uint32_t li = 0, qi = 0, qn = 0, cost = 0;
+    for (uint32_t step = 1; step < m; step++) {
+        uint32_t pick[2];
+        for (int k = 0; k < 2; k++) {
+            const bool leaf = li < m && (qi >= qn || sorted[li] <= queue[qi]);
+            pick[k] = leaf ? sorted[li++] : queue[qi++];
+        }
+        const uint32_t sum = pick[0] + pick[1];
+        cost += sum;
+        queue[qn++] = sum;
+    }
+    return cost;
+}
+
+struct StoredProbe { uint32_t static_len, extra_bits, used; };
+
+// Exact static_len, exact extra bits and the number of used codes of one block's histograms.
+ZWZ_HD StoredProbe probe_block(const uint16_t* lfreq, const uint16_t* dfreq) {
+    StoredProbe r{0, 0, 0};
+    uint32_t dused = 0;
+    for (uint32_t n = 0; n < kLCodes; n++) {
+        const uint32_t f = lfreq[n];
+        if (!f) continue;
+        const uint32_t x = n >= 257u ? length_extra_bits(n - 257u) : 0u;
+        r.static_len += f * (static_lit_len(n) + x); r.extra_bits += f * x; r.used++;
+    }
+    for (uint32_t n = 0; n < kDCodes; n++) {
+        const uint32_t f = dfreq[n];
+        if (!f) continue;
+        r.static_len += f * (5u + dist_extra_bits(n)); r.extra_bits += f * dist_extra_bits(n); dused++;
+    }
+    r.used += dused;
+    return r;
+}
+
+ZWZ_HD bool stored_is_certain(const StoredProbe& pr, uint32_t huff_lit, uint32_t huff_dist, uint32_t stored_len, bool stored_ok) {
+    if (!stored_ok) return false;
+    const uint32_t opt_lb = huff_lit + huff_dist + pr.extra_bits + 14u + 12u + (pr.used + 5u) / 6u;
+    return stored_len + 4u <= ((opt_lb + 10u) >> 3) && stored_len + 4u <= ((pr.static_len + 10u) >> 3);
+}
+
 // Bits of one symbol under a block's codes, LSB-first.  Literal: entry == 0, lit = byte.
 // Match: entry = packed (len, dist).  At most 15+5+15+13 = 48 bits.
 ZWZ_HD void symbol_bits(const uint16_t* lcode, const uint8_t* llen, const uint16_t* dcode, const uint8_t* dlen,

@@ -31,13 +31,37 @@ struct InflateTables {
     uint16_t lit_sym[288], dist_sym[32];     // symbols sorted by (length, symbol)
 };
 
+// LSB-first bit reader over payload bytes [0, n).  `in` is either the payload itself (mask = ~0)
+// or a power-of-two ring that holds a sliding window of it (mask = ring size - 1, the first 8 ring
+// bytes mirrored past its end), indexed by absolute payload position.
 struct BitReader {
-    const uint8_t* in; uint32_t n, pos;
+    const uint8_t* in; uint32_t n, pos, mask;
     uint64_t hold; uint32_t bits;
-    ZWZ_HD void init(const uint8_t* p, uint32_t len) { in = p; n = len; pos = 0; hold = 0; bits = 0; }
-    // top up to >= 56 bits while input lasts
+    ZWZ_HD void init(const uint8_t* p, uint32_t len, uint32_t ring_mask = 0xffffffffu) {
+        in = p; n = len; pos = 0; mask = ring_mask; hold = 0; bits = 0;
+    }
+    ZWZ_HD uint64_t load8(uint32_t at) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t o = at & mask;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(in) + (o >> 2);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], o & 3u);
+        return ((uint64_t)hi << 32) | lo;
+#else
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < 8 && at + i < n; i++) v |= (uint64_t)in[(at + i) & mask] << (8 * i);
+        return v;
+#endif
+    }
+    // top up to >= 56 bits while input lasts: one 8-byte read instead of a byte loop
     ZWZ_HD void refill() {
-        while (bits <= 56 && pos < n) { hold |= (uint64_t)in[pos++] << bits; bits += 8; }
+        if (bits > 56 || pos >= n) return;
+        uint32_t adv = (63u - bits) >> 3;            // whole bytes that fit
+        const uint32_t avail = n - pos;
+        uint64_t w = load8(pos);
+        if (adv > avail) adv = avail;
+        if (adv < 8) w &= (1ull << (8 * adv)) - 1ull;   // never expose bytes past the payload or the budget
+        hold |= w << bits;
+        pos += adv; bits += 8 * adv;
     }
     ZWZ_HD uint32_t peek(uint32_t k) const { return (uint32_t)(hold & ((1ull << k) - 1ull)); }
     ZWZ_HD void drop(uint32_t k) { hold >>= k; bits -= k; }
@@ -108,8 +132,8 @@ struct InflateState {
 };
 
 // zlib stream header (RFC 1950).  Returns false (status set) if decoding cannot start.
-ZWZ_HD bool inflate_begin(InflateState& st, const uint8_t* in, uint32_t n) {
-    st.br.init(in, n); st.out_pos = 0; st.last = 0; st.status = kInfRunning;
+ZWZ_HD bool inflate_begin(InflateState& st, const uint8_t* in, uint32_t n, uint32_t ring_mask = 0xffffffffu) {
+    st.br.init(in, n, ring_mask); st.out_pos = 0; st.last = 0; st.status = kInfRunning;
     uint32_t cmf, flg;
     if (!st.br.take(8, cmf) || !st.br.take(8, flg)) { st.status = kInfNeedInput; return false; }
     if (((cmf << 8) + flg) % 31u || (cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 0x20u)) { st.status = kInfDataError; return false; }

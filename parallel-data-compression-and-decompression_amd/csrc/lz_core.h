@@ -105,8 +105,8 @@ struct MaskWriter {
 
 struct ParseResult { uint32_t n_sym; uint32_t n_match; uint32_t last_is_match; };
 
-template <class EntryFn>
-ZWZ_HD ParseResult lz_parse(EntryFn entries /* (p, which32) -> packed entry */, const uint64_t* has128, uint32_t L,
+template <class EntryFn, class HasFn>
+ZWZ_HD ParseResult lz_parse(EntryFn entries /* (p, which32) -> packed entry */, HasFn has128 /* word index -> mask */, uint32_t L,
                             uint64_t* sym, uint64_t* mst, uint64_t* m32) {
     const uint32_t nwords = (L + 63) >> 6;
     // masks are built word by word: the walk is monotone in position
@@ -143,12 +143,13 @@ ZWZ_HD ParseResult lz_parse(EntryFn entries /* (p, which32) -> packed entry */, 
         if (b < kMinMatch) {
             // nothing pending: every position without an e128 record is a plain literal
             uint32_t wi = p >> 6;
-            uint64_t bits = has128[wi] >> (p & 63);
+            uint64_t bits = has128(wi) >> (p & 63);
             if (bits == 0) {
+                uint64_t hw = 0;
                 wi++;
-                while (wi < nwords && has128[wi] == 0) wi++;
+                while (wi < nwords && (hw = has128(wi)) == 0) wi++;
                 if (wi >= nwords) break;
-                p = (wi << 6) + (uint32_t)__builtin_ctzll(has128[wi]);
+                p = (wi << 6) + (uint32_t)__builtin_ctzll(hw);
             } else {
                 p += (uint32_t)__builtin_ctzll(bits);
             }

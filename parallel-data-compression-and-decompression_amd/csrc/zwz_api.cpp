@@ -137,7 +137,7 @@ int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
 int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                           uint8_t* d_out, uint64_t out_stride, uint32_t* d_out_len, uint32_t* d_status) {
     if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len || !d_status))) return ZWZ_E_INVALID;
-    if (out_stride < ZWZ_CHUNK_SIZE) return ZWZ_E_INVALID;
+    if (out_stride < ZWZ_CHUNK_SIZE || ((uintptr_t)d_in & 15u)) return ZWZ_E_INVALID;
     HIPCHK(hipSetDevice(c->device));
     InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status};
     if (c->profiling) HIPCHK(hipEventRecord(c->ev_inf[0], c->stream));

@@ -17,6 +17,7 @@ constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
 constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
 constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes;   // 147136 of 163840
+constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept

@@ -178,22 +178,52 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz_parse: the sequential lazy-match walk, one lane per chunk (many chunks in flight).
-__global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n, const uint2* __restrict__ entries,
-                                                      const uint64_t* __restrict__ has128, uint64_t* __restrict__ sym,
-                                                      uint64_t* __restrict__ mst, uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info) {
-    const uint32_t chunk = blockIdx.x * 64 + threadIdx.x;
+// lz_parse: the sequential lazy-match walk, one wave per chunk.  The walk itself is scalar (every
+// lane runs the same control flow on wave-uniform values); the wave exists to fetch the records:
+// 64 consecutive records per coalesced 512-byte load, the next window prefetched, lookups served
+// by v_readlane.  (One lane per chunk dragged the whole 8 B/position table through uncoalesced
+// loads: 139 ms for 50k text chunks.)
+__global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n,
+                                                                const uint2* __restrict__ entries, const uint64_t* __restrict__ has128,
+                                                                uint64_t* __restrict__ sym, uint64_t* __restrict__ mst,
+                                                                uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info) {
+    const uint32_t chunk = blockIdx.x * (kParseThreads / 64) + (threadIdx.x >> 6);
     if (chunk >= n) return;
+    const uint32_t lane = lane_id();
     const uint2* ent = entries + (size_t)chunk * kEntryStride;
     const uint32_t L = in_len[chunk];
-    ParseResult r = lz_parse([ent](uint32_t p, uint32_t sel) { uint2 e = ent[p]; return sel ? e.y : e.x; },
-                             has128 + (size_t)chunk * kMaskWords, L, sym + (size_t)chunk * kMaskWords,
+    uint32_t win = 0xffffffffu;             // first position of the window held in `cur`
+    uint32_t cx = 0, cy = 0, nx = 0, ny = 0;   // current / prefetched window: e128 in x, e32 in y
+    uint64_t cmask = 0;                        // positions of the current window with an e128 record
+    const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
+    auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t {
+        p = __builtin_amdgcn_readfirstlane(p);
+        sel = __builtin_amdgcn_readfirstlane(sel);
+        const uint32_t w = p & ~63u;
+        if (w != win) {                     // wave-uniform
+            if (w == win + 64u) { cx = nx; cy = ny; } else { const uint2 e = ent[w + lane]; cx = e.x; cy = e.y; }
+            win = w;
+            if (w + 64u < kEntryStride) { const uint2 e = ent[w + 64u + lane]; nx = e.x; ny = e.y; }   // rows are 65536 records long
+            cmask = __ballot(cx != 0);
+        }
+        const uint32_t vx = __builtin_amdgcn_readlane(cx, p & 63u), vy = __builtin_amdgcn_readlane(cy, p & 63u);
+        return sel ? vy : vx;
+    };
+    // the mask word of the window in registers comes from a ballot; skipping ahead over literal
+    // runs reads lz_match's has128 words instead of whole record windows
+    auto has = [&](uint32_t wi) -> uint64_t {
+        wi = __builtin_amdgcn_readfirstlane(wi);
+        return (wi << 6) == win ? cmask : hm[wi];
+    };
+    ParseResult r = lz_parse(lookup, has, L, sym + (size_t)chunk * kMaskWords,
                              mst + (size_t)chunk * kMaskWords, m32 + (size_t)chunk * kMaskWords);
-    ChunkInfo ci;
-    ci.n_sym = r.n_sym;
-    const uint32_t s_in = (r.n_sym > 0 && !r.last_is_match) ? r.n_sym - 1 : r.n_sym;
-    ci.n_blocks = s_in / kSymsPerBlock + 1;
-    info[chunk] = ci;
+    if (lane == 0) {
+        ChunkInfo ci;
+        ci.n_sym = r.n_sym;
+        const uint32_t s_in = (r.n_sym > 0 && !r.last_is_match) ? r.n_sym - 1 : r.n_sym;
+        ci.n_blocks = s_in / kSymsPerBlock + 1;
+        info[chunk] = ci;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,13 +320,32 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
-// plan: one wave per (chunk, block); lane 0 runs zlib's tree construction with its scratch in LDS.
+// plan: one wave per (chunk, block).  First the stored-block shortcut (huff_core.h): the wave rank-
+// sorts the histogram, lane 0 merges it into the optimal Huffman cost, and if that lower bound
+// already forces "stored" the block is done.  Otherwise lane 0 runs zlib's exact tree construction
+// with its scratch in LDS.
+static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint32_t n, uint16_t* sorted, uint32_t* m_out) {
+    // ascending order of the non-zero counts; ties by symbol (any order works for the cost)
+    const uint32_t lane = lane_id();
+    uint32_t used = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t fi = i < n ? freq[i] : 0u;
+        uint32_t rank = 0;
+        if (fi) for (uint32_t j = 0; j < n; j++) { const uint32_t fj = freq[j]; rank += (fj != 0u) & ((fj < fi) | ((fj == fi) & (j < i))); }
+        if (fi) sorted[rank] = (uint16_t)fi;
+        used += (uint32_t)__popcll(__ballot(fi != 0));
+    }
+    *m_out = used;
+}
+
 __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
                                                   BlockOut* __restrict__ plans) {
     __shared__ TreeScratch ts;
     __shared__ BlockCodes bc;
     __shared__ uint32_t hdr[kHdrWords];
     __shared__ uint16_t lf[kLCodes], df[kDCodes];
+    __shared__ uint16_t sorted[kLCodes];
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
     if (b >= info[chunk].n_blocks) return;
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
@@ -305,10 +354,35 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) hdr[i] = 0;
     __syncthreads();
+    const uint32_t last = b + 1 == info[chunk].n_blocks;
+    const uint32_t stored_len = bi->end - bi->start;
+    const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
+
+    // ---- shortcut: is "stored" already certain?
+    uint32_t m_l = 0, m_d = 0, certain = 0;
+    if (stored_ok && stored_len > 0) {
+        uint32_t* queue = ts.heap;                      // scratch not yet in use
+        wave_rank_sort(lf, kLCodes, sorted, &m_l);
+        __syncthreads();
+        uint32_t hl = 0, hd = 0;
+        if (threadIdx.x == 0) hl = huffman_cost_sorted(sorted, m_l, queue);
+        __syncthreads();
+        wave_rank_sort(df, kDCodes, sorted, &m_d);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            hd = huffman_cost_sorted(sorted, m_d, queue);
+            const StoredProbe pr = probe_block(lf, df);
+            certain = stored_is_certain(pr, hl, hd, stored_len, stored_ok) ? 1u : 0u;
+        }
+        certain = __builtin_amdgcn_readfirstlane(certain);
+    }
+    if (certain) {
+        if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
+        return;   // codes are never read for stored blocks
+    }
+
     if (threadIdx.x == 0) {
-        const uint32_t last = b + 1 == info[chunk].n_blocks;
-        const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
-        BlockPlan bp = plan_block(ts, lf, df, bi->end - bi->start, stored_ok, last, bc, hdr);
+        BlockPlan bp = plan_block(ts, lf, df, stored_len, stored_ok, last, bc, hdr);
         bo->type = bp.type; bo->hdr_bits = bp.hdr_bits; bo->body_bits = bp.body_bits;
         bo->eob_len = bc.llen[256]; bo->eob_code = bc.lcode[256];
     }
@@ -378,6 +452,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         s_rank[tid] = wbase + incl - cnt;
     }
     for (uint32_t b = 0; b < ci.n_blocks; b++) {
+        if (bo[b].type == kStored) continue;   // stored blocks carry no codes (plan may not have built any)
         for (uint32_t i = tid; i < kLCodes; i += kEncodeThreads) { s_lcode[b * 288 + i] = bo[b].lcode[i]; s_llen[b * 288 + i] = bo[b].llen[i]; }
         if (tid < kDCodes) { s_dcode[b * 32 + tid] = bo[b].dcode[tid]; s_dlen[b * 32 + tid] = bo[b].dlen[tid]; }
     }
@@ -426,10 +501,34 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         }
     }
 
-    // symbols: one position per thread per step; exclusive scan of code lengths gives bit offsets
-    uint32_t carry = 0;        // symbol bits emitted before this step (all Huffman blocks)
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
     uint8_t* s_out8 = reinterpret_cast<uint8_t*>(s_out);
+    bool all_stored = true;
+    for (uint32_t b = 0; b < ci.n_blocks; b++) all_stored = all_stored && s_blk[b].type == kStored;
+    if (all_stored) {
+        // incompressible chunk: every block is a byte copy behind a 5-byte header; no code lengths,
+        // no scan, no barriers -- four input bytes per thread per trip
+        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
+        for (uint32_t i = tid * 4u; i < L; i += kEncodeThreads * 4u) {
+            uint32_t w;
+            if (i + 4u <= ((L + 15u) & ~15u)) w = d32[i >> 2];   // slot readable to the next multiple of 16
+            else { w = 0; for (uint32_t j = 0; j < 4 && i + j < L; j++) w |= (uint32_t)data[i + j] << (8 * j); }
+            uint32_t blk = 0;
+            while (blk + 1 < ci.n_blocks && i >= s_blk[blk].end) blk++;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t p = i + j;
+                if (p >= L) break;
+                if (p >= s_blk[blk].end) blk++;
+                const uint32_t byte = (w >> (8 * j)) & 0xffu;
+                a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
+                const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
+                if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
+            }
+        }
+    } else {
+    // symbols: one position per thread per step; exclusive scan of code lengths gives bit offsets
+    uint32_t carry = 0;        // symbol bits emitted before this step (all Huffman blocks)
     for (uint32_t base = 0; base < (nwords << 6); base += kEncodeThreads) {
         const uint32_t p = base + tid, wi = p >> 6, bit = p & 63;
         uint64_t v = 0; uint32_t nb = 0, blk = 0;
@@ -468,6 +567,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         }
         carry += total;
     }
+    }
 
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
     for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
@@ -489,10 +589,16 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 
 // ------------------------------------------------------------------------------------------------
 // inflate: one wave per chunk.  Lane 0 owns the bit reader and the tables; the wave moves bytes.
+// The payload reaches lane 0 through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave
+// (16 bytes per lane, coalesced): a decode call consumes < 1 KiB, so topping the ring up to
+// pos + 1 KiB before every call keeps lane 0 off global memory entirely.
+constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
+
 struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
+    __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
 __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
@@ -504,17 +610,35 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
     const uint32_t chunk = blockIdx.x * (kInflateThreads / 64) + wave;
     if (chunk >= n) return;
     InflateWaveMem& m = s_mem[wave];
-    const uint8_t* src = in + in_off[chunk];
+    const uint8_t* src = in + in_off[chunk];          // 16-byte aligned (API contract)
     uint8_t* dst = out + (size_t)chunk * out_stride;
     const uint32_t nin = in_len[chunk];
+    const uint32_t nin16 = (nin + 15u) & ~15u;         // readable extent (API contract)
+
+    uint32_t fill_end = 0;                             // ring holds payload bytes [fill_end - 2048, fill_end)
+    auto top_up = [&](uint32_t pos) {                  // wave-uniform: make [pos, pos + 1 KiB) resident
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        if (fill_end + kInfRing < pos + kInfFill) fill_end = pos & ~(kInfFill - 1u);   // jumped (stored block): restart
+        while (fill_end < pos + kInfFill && fill_end < nin16) {
+            const uint32_t o = fill_end + lane * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o < nin16) v = *reinterpret_cast<const uint4*>(src + o);
+            *reinterpret_cast<uint4*>(m.ring + (o & (kInfRing - 1u))) = v;
+            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(m.ring + kInfRing) = v;   // wrap-around mirror
+            fill_end += kInfFill;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
 
     InflateState st;
+    top_up(0);
     uint32_t go = 0;
-    if (lane == 0) go = inflate_begin(st, src, nin) ? 1u : 0u;
+    if (lane == 0) go = inflate_begin(st, m.ring, nin, kInfRing - 1u) ? 1u : 0u;
     go = __builtin_amdgcn_readfirstlane(go);
     uint32_t fenced = 0;      // every output byte below this offset is visible to the whole wave
     while (go) {
         uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
+        top_up(st.br.pos);
         if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, m.lens, soff, slen); }
         kind = __builtin_amdgcn_readfirstlane(kind);
         if (kind == kBlkStop) break;
@@ -534,6 +658,7 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
             uint32_t done = 0;
             while (!done) {
                 uint32_t k = 0;
+                top_up(st.br.pos);
                 if (lane == 0) { bool d; k = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d); done = d; }
                 k = __builtin_amdgcn_readfirstlane(k); done = __builtin_amdgcn_readfirstlane(done);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // lane 0's LDS batch -> all lanes
@@ -584,7 +709,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n * kTilesPerChunk), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst, a.m32,
                        a.info, a.blocks);
