@@ -125,56 +125,94 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz_match: records for the positions of one 16 Ki tile.  LDS holds bytes [org, te+266) and links
-// [org, te) where org = tile start - 32506 (the furthest zlib may look back).
+// lz_match: per-position match records.  One workgroup walks one chunk tile by tile (16 Ki positions
+// per tile) with the history zlib may look at -- bytes and links of the last 32506 positions --
+// resident in LDS.  Between tiles the window is slid inside LDS and only the next tile's own
+// 16 KiB of bytes + 32 KiB of links come from HBM, fetched into registers while the current tile
+// is being searched (a tile-per-workgroup version re-read the whole 147 KB window per tile and
+// spent 58% of its wave-cycles waiting on it).
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t chunk = blockIdx.x / kTilesPerChunk, tile = blockIdx.x % kTilesPerChunk;
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
-    const uint32_t ts = tile * kTile;
-    if (ts >= L && !(tile == 0)) return;
-    const uint32_t te = min(ts + kTile, L);
-    const uint32_t org = ts > kMaxDist ? (ts - kMaxDist) & ~7u : 0u;
-    const uint32_t data_end = min(L, te + kMaxMatch + 8u);            // bytes we may touch
-    const uint32_t data_words = (te + kMaxMatch + 8u - org + 3u) >> 2; // LDS extent (zero padded)
+    if (L == 0) return;
     uint8_t* sdata = smem;
     uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
-
-    const uint8_t* gdata = in + in_off[chunk];
-    const uint16_t* glink = links + (size_t)chunk * kLinkStride;
-    {   // stage the window with 16-byte loads, eight in flight per thread before the first LDS
-        // store (one load per loop trip would leave each wave waiting out a full HBM round trip).
-        // Chunk base is 16-byte aligned (API contract); org is a multiple of 8.
-        const uint32_t data_bytes = data_end > org ? data_end - org : 0u;
-        const uint32_t nvec = data_bytes >> 4;
-        const uint4* g4 = reinterpret_cast<const uint4*>(gdata + org);
-        uint4* s4 = reinterpret_cast<uint4*>(sdata);
-        copy_vec16(s4, g4, nvec);
-        uint32_t* s32 = reinterpret_cast<uint32_t*>(sdata);
-        for (uint32_t i = (nvec << 2) + threadIdx.x; i < data_words; i += kMatchThreads) {   // ragged tail + zero pad
-            uint32_t v = 0, b = org + (i << 2);
-            for (uint32_t k = 0; k < 4; k++) if (b + k < data_end) v |= (uint32_t)gdata[b + k] << (8 * k);
-            s32[i] = v;
-        }
-        const uint32_t lvec = (te - org + 7u) >> 3;   // 8 links per 16 bytes; the row has 65536 entries
-        const uint4* l4 = reinterpret_cast<const uint4*>(glink + org);
-        uint4* sl4 = reinterpret_cast<uint4*>(slink);
-        copy_vec16(sl4, l4, lvec);
-    }
-    __syncthreads();
-
+    uint4* sd4 = reinterpret_cast<uint4*>(sdata);
+    uint4* sl4 = reinterpret_cast<uint4*>(slink);
+    const uint4* gd4 = reinterpret_cast<const uint4*>(in + in_off[chunk]);                    // 16-byte aligned (API contract)
+    const uint4* gl4 = reinterpret_cast<const uint4*>(links + (size_t)chunk * kLinkStride);
     uint2* ent = entries + (size_t)chunk * kEntryStride;
     uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
-    const uint32_t tile_words_end = (te + 63u) & ~63u;
-    for (uint32_t p = ts + threadIdx.x; p < tile_words_end; p += kMatchThreads) {
-        uint32_t e128 = 0, e32 = 0;
-        if (p < te) lz_search(sdata, slink, org, p, L, e128, e32);
-        if (p < te) ent[p] = make_uint2(e128, e32);
-        const uint64_t m = __ballot(e128 != 0);
-        if (lane_id() == 0) hm[p >> 6] = m;
+    const uint32_t ntiles = (L + kTile - 1) / kTile;
+    const uint32_t dvec_total = (L + 15u) >> 4;     // the slot is readable to L rounded up to 16; bytes past L
+                                                    // never influence a result (compares are capped at the lookahead)
+    // vectors [dlo, dhi) of data and [llo, lhi) of links are what tile t adds to the window
+#define ZWZ_TILE_RANGE(t)                                                                          \
+    const uint32_t te_ = min(((t) + 1) * kTile, L), pe_ = (t) ? min((t) * kTile, L) : 0u;          \
+    const uint32_t dlo = (t) ? min((pe_ + kMaxMatch + 8u + 15u) >> 4, dvec_total) : 0u;            \
+    const uint32_t dhi = min((te_ + kMaxMatch + 8u + 15u) >> 4, dvec_total);                       \
+    const uint32_t llo = (pe_ + 7u) >> 3, lhi = (te_ + 7u) >> 3;
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint4 pd0 = z4, pd1 = z4, pl0 = z4, pl1 = z4;   // next tile's bytes / links in flight
+#define ZWZ_PREFETCH(t)                                                                            \
+    {                                                                                              \
+        ZWZ_TILE_RANGE(t)                                                                          \
+        if (dlo + tid < dhi) pd0 = gd4[dlo + tid];                                                 \
+        if (dlo + tid + kMatchThreads < dhi) pd1 = gd4[dlo + tid + kMatchThreads];                 \
+        if (llo + tid < lhi) pl0 = gl4[llo + tid];                                                 \
+        if (llo + tid + kMatchThreads < lhi) pl1 = gl4[llo + tid + kMatchThreads];                 \
     }
+    uint32_t org = 0;
+    ZWZ_PREFETCH(0u)
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint32_t ts = t * kTile, te = min(ts + kTile, L);
+        {   // registers -> LDS window whose first byte is position org
+            ZWZ_TILE_RANGE(t)
+            if (dlo + tid < dhi) sd4[dlo + tid - (org >> 4)] = pd0;
+            if (dlo + tid + kMatchThreads < dhi) sd4[dlo + tid + kMatchThreads - (org >> 4)] = pd1;
+            if (llo + tid < lhi) sl4[llo + tid - (org >> 3)] = pl0;
+            if (llo + tid + kMatchThreads < lhi) sl4[llo + tid + kMatchThreads - (org >> 3)] = pl1;
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) ZWZ_PREFETCH(t + 1)     // in flight during the search below
+
+        const uint32_t tile_words_end = (te + 63u) & ~63u;
+        for (uint32_t p = ts + tid; p < tile_words_end; p += kMatchThreads) {
+            uint32_t e128 = 0, e32 = 0;
+            if (p < te) lz_search(sdata, slink, org, p, L, e128, e32);
+            if (e128) ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
+            const uint64_t m = __ballot(e128 != 0);
+            if (lane_id() == 0) hm[p >> 6] = m;
+        }
+        if (t + 1 == ntiles) break;
+
+        // slide: the next tile starts at te and may look back 32506 positions
+        const uint32_t new_org = te > kMaxDist ? (te - kMaxDist) & ~15u : 0u;
+        const uint32_t delta = new_org - org;
+        __syncthreads();
+        if (delta) {
+            ZWZ_TILE_RANGE(t)
+            (void)dlo; (void)llo;
+            const uint32_t dn = dhi - (new_org >> 4), ln = lhi - (new_org >> 3);   // vectors that stay
+            const uint32_t dsh = delta >> 4, lsh = delta >> 3;
+            uint4 rd[4] = {z4, z4, z4, z4}, rl[6] = {z4, z4, z4, z4, z4, z4};
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) rd[u] = sd4[i + dsh]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) rl[u] = sl4[i + lsh]; }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) sd4[i] = rd[u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) sl4[i] = rl[u]; }
+            org = new_org;
+        }
+    }
+#undef ZWZ_TILE_RANGE
+#undef ZWZ_PREFETCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -194,17 +232,21 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     const uint32_t L = in_len[chunk];
     uint32_t win = 0xffffffffu;             // first position of the window held in `cur`
     uint32_t cx = 0, cy = 0, nx = 0, ny = 0;   // current / prefetched window: e128 in x, e32 in y
-    uint64_t cmask = 0;                        // positions of the current window with an e128 record
+    uint64_t cmask = 0, nmask = 0;             // has128 words of the current / prefetched window
     const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t {
         p = __builtin_amdgcn_readfirstlane(p);
         sel = __builtin_amdgcn_readfirstlane(sel);
         const uint32_t w = p & ~63u;
         if (w != win) {                     // wave-uniform
-            if (w == win + 64u) { cx = nx; cy = ny; } else { const uint2 e = ent[w + lane]; cx = e.x; cy = e.y; }
+            // records exist only where lz_match found something: gate every lane on its has128 bit
+            if (w == win + 64u) { cx = nx; cy = ny; cmask = nmask; }
+            else { cmask = hm[w >> 6]; const uint2 e = ent[w + lane]; const bool on = (cmask >> lane) & 1ull; cx = on ? e.x : 0u; cy = on ? e.y : 0u; }
             win = w;
-            if (w + 64u < kEntryStride) { const uint2 e = ent[w + 64u + lane]; nx = e.x; ny = e.y; }   // rows are 65536 records long
-            cmask = __ballot(cx != 0);
+            if (w + 64u < kEntryStride) {   // rows are 65536 records long
+                nmask = hm[(w >> 6) + 1u];
+                const uint2 e = ent[w + 64u + lane]; const bool on = (nmask >> lane) & 1ull; nx = on ? e.x : 0u; ny = on ? e.y : 0u;
+            }
         }
         const uint32_t vx = __builtin_amdgcn_readlane(cx, p & 63u), vy = __builtin_amdgcn_readlane(cy, p & 63u);
         return sel ? vy : vx;
@@ -706,7 +748,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(lz_match_kernel, dim3(a.n * kTilesPerChunk), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
+    hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);

@@ -2,7 +2,7 @@
 # GPU-box helper: rocprofv3 kernel stats + PMC passes of one bench workload.  usage: tools_prof.sh <workload> <files> <tag>
 W=${1:-random}; F=${2:-2000}; TAG=${3:-r01}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG_$W; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${TAG}_$W; mkdir -p $O
 ARGS="$R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $W --files $F"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $ARGS > $O/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc1 -- python3 $ARGS > $O/pmc1.log 2>&1
