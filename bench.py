@@ -208,6 +208,11 @@ def main():
         algo_bytes = (raw_bytes + payload_bytes) if dom != "inflate" else (payload_bytes + back_bytes)
         algo_per_launch = algo_bytes / (dom_launches / prof_passes)
         achieved = algo_per_launch / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath) and args.files == 10000 and args.file_bytes == 262144:
+            # PMC pass of this same command, collected separately (tools_prof.sh); null if not measured
+            traffic = json.load(open(tpath)).get(dom.replace("lz_", "lz_"), {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "compress+decompress GB/s (raw bytes / (deflate + inflate time)), .zwz bit-exact",
             "value": round(world * raw_bytes * args.steps / elapsed / 1e9, 3), "unit": "GB/s",
@@ -221,7 +226,7 @@ def main():
             "payload_ratio": round(payload_bytes / raw_bytes, 4), "roundtrip_property_ok": ok,
             "stage_ms_per_pass": {k: round(v / prof_passes, 3) for k, v in stage.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(algo_per_launch), "launch_ms": round(dom_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

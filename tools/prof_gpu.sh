@@ -10,4 +10,4 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ID
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc3 -- python3 $ARGS > $O/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc4 -- python3 $ARGS > $O/pmc4.log 2>&1
 find $O -name "*.csv" | head -20
-python3 $R/tools_prof_summary.py $O
+python3 $R/tools/prof_summary.py $O
