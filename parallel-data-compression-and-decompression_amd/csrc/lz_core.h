@@ -44,9 +44,12 @@ ZWZ_HD uint32_t match_len_from(const uint8_t* data, uint32_t a, uint32_t b, uint
 // Match records of position p.  data/link are window views: data[i - org], link[i - org] hold
 // byte i / chain predecessor of position i (0 = NIL).  L = chunk length.
 //
-// Candidate filter (same accept/reject decisions as zlib's longest_match, fewer loads): a
-// candidate can only beat `best` if it agrees with the scan at offset `best`; while best is still
-// 2 that is the 3-byte prefix itself, tested on one cached word.
+// Candidate filter: a candidate can only beat `best` if it agrees with the scan on bytes
+// 0..best; the loop tests the three bytes best-2..best on one word (for best == 2 that is the
+// trigram itself, afterwards it is zlib's scan_end test, one byte stronger).  The link of the
+// next candidate is read together with the filter word, so a rejected candidate costs one LDS
+// round trip, and every stop condition is folded into the loop predicate (a version with early
+// exits spent ~35 exec-mask SALU instructions per candidate).
 ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
                       uint32_t& e128, uint32_t& e32) {
     e128 = 0; e32 = 0;
@@ -59,32 +62,29 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     const uint32_t nice = lookahead < kNiceLen ? lookahead : kNiceLen;
     const uint32_t limit = p > kMaxDist ? p - kMaxDist : 0;
     const uint32_t pp = p - org;
-    const uint32_t head4 = load_u32(data, pp);           // scan[0..3]
-    uint32_t best = kMinMatch - 1, best_pos = 0, n = 0;
-    uint32_t scan_at_best = 0;                           // scan[best], valid once best >= 3
-    bool have32 = false;
-    for (;;) {
+    uint32_t best = kMinMatch - 1, best_pos = 0, n = 0, snap = 0;
+    uint32_t scan_w = load_u32(data, pp);                // scan[best-2 .. best+1]
+    bool have32 = false, go = true;
+    do {
         const uint32_t c = cur - org;
-        uint32_t len = 0;
-        if (best < kMinMatch) {
-            const uint32_t x = load_u32(data, c) ^ head4;
-            if ((x & 0xffffffu) == 0) len = x ? 3u : match_len_from(data, c, pp, 4u, max_len);
-        } else if (data[c + best] == scan_at_best) {
-            len = match_len_from(data, c, pp, 0u, max_len);
-        }
-        if (len > max_len) len = max_len;
-        if (len > best) {
-            best = len; best_pos = cur;
-            if (len >= nice) break;
-            scan_at_best = data[pp + best];
+        const uint32_t x = load_u32(data, c + best - 2u) ^ scan_w;
+        const uint32_t next = link[c];
+        bool nice_stop = false;
+        if ((x & 0xffffffu) == 0) {                      // rare: worth a full comparison
+            uint32_t len = match_len_from(data, c, pp, 0u, max_len);
+            if (len > best) {
+                best = len; best_pos = cur;
+                nice_stop = len >= nice;
+                if (!nice_stop) scan_w = load_u32(data, pp + best - 2u);
+            }
         }
         n++;
-        if (n == kShortChain) { have32 = true; e32 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0; }
-        cur = link[c];
-        if (cur <= limit || n == kMaxChain) break;
-    }
+        if (n == kShortChain && !nice_stop) { have32 = true; snap = entry_pack(best, p - best_pos); }
+        cur = next;
+        go = !nice_stop && cur > limit && n < kMaxChain;
+    } while (go);
     e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0;
-    if (!have32) e32 = e128;
+    e32 = have32 ? (entry_len(snap) >= kMinMatch ? snap : 0u) : e128;
     // TOO_FAR: a minimum-length match further than 4096 back is dropped (deflate_slow)
     if (entry_len(e128) == kMinMatch && entry_dist(e128) > kTooFar) e128 = 0;
     if (entry_len(e32) == kMinMatch && entry_dist(e32) > kTooFar) e32 = 0;
