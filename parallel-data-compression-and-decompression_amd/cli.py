@@ -1,0 +1,171 @@
+"""`python -m <package>.cli compress|decompress <src> <dst>` -- the reference's command line
+(main.cpp:78-159) for a one-process-per-GPU launch under torchrun.
+
+What the reference does with MPI maps onto torch.distributed (backend "nccl" = RCCL
+over xGMI when GPUs are present, "gloo" otherwise):
+
+    MPI_Bcast of the record-file *path* (main.cpp:27,35), contents via a shared file system
+        -> broadcast of the sorted list *contents* from rank 0; every rank writes its own copy, so
+           ranks need no shared file system for the list
+    rank -> files: line i of the list goes to rank i mod N (compression.cpp:38-41), one shard per rank
+        -> unchanged; no data-path collective
+    MPI_Barrier + MPI_Wtime banner (main.cpp:144-155)
+        -> dist.barrier() + the same banner text
+    (addition, --gather) per-shard .zwz blobs collected on rank 0 for hosts without a shared output
+        directory; the reference has no gather (every rank writes compressed_<rank>.zwz itself)
+
+Decompression is a single-rank job in the reference (main.cpp:61-68) and here.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def broadcast_bytes(data, src=0):
+    """Rank src's bytes on every rank (length first, then payload)."""
+    import torch
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return data
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(data) if dist.get_rank() == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if dist.get_rank() == src:
+        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    if buf.numel():
+        dist.broadcast(buf, src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def gather_blobs(blob, dst=0):
+    """Every rank's bytes on rank dst (list indexed by rank), None elsewhere."""
+    import torch
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [blob]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(blob)], dtype=torch.int64, device=dev))
+    cap = max(int(s.item()) for s in sizes)
+    mine = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    if blob:
+        mine[:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)          # RCCL has no gatherv; shards are padded to the largest
+    if rank != dst:
+        return None
+    return [bytes(p[:int(s.item())].cpu().numpy().tobytes()) for p, s in zip(parts, sizes)]
+
+
+def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=None, sort_fn=None, count_fn=None,
+        gather=False, out=sys.stdout):
+    """The reference's main() flow.  *_fn default to the GPU codec; tests inject stand-ins to
+    exercise the orchestration without a GPU."""
+    start = time.perf_counter()
+    dist = _dist()
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if compress_fn is None or decompress_fn is None or sort_fn is None or count_fn is None:
+        from . import count_non_empty_lines, do_compression, do_decompression, sort_files_by_size
+        compress_fn = compress_fn or do_compression
+        decompress_fn = decompress_fn or do_decompression
+        sort_fn = sort_fn or sort_files_by_size
+        count_fn = count_fn or count_non_empty_lines
+
+    source_path, output_path = source_path.rstrip("/") or source_path, output_path.rstrip("/") or output_path  # main.cpp:72-76
+    print("source_path: %s\noutput_path: %s" % (source_path, output_path), file=out)
+    if operation not in ("compress", "decompress"):
+        print("Invalid operation: %s. Please use 'compress' or 'decompress'." % operation, file=sys.stderr)
+        return 1
+    if rank == 0:                                                   # main.cpp:105-129
+        if not os.path.exists(source_path):
+            print("Source path does not exist.", file=sys.stderr)
+            return 1
+        if not os.path.exists(output_path):
+            os.mkdir(output_path, 0o777)
+        elif not os.path.isdir(output_path):
+            print("Output path is not a directory.", file=sys.stderr)
+            return 1
+    if world > 1:
+        dist.barrier()
+
+    rc = 0
+    if operation == "compress":
+        listing = b""
+        if rank == 0:
+            print("Compressing folder: %s" % source_path, file=out)
+            record = os.environ.get("ZWZ_FILE_RECORD") or sort_fn(source_path)
+            print("File record saved location: %s" % record, file=out)
+            with open(record, "rb") as f:
+                listing = f.read()
+        listing = broadcast_bytes(listing, 0)
+        with tempfile.NamedTemporaryFile(prefix="zwz_list_r%d_" % rank, suffix=".txt", delete=False) as f:
+            f.write(listing)
+            local_record = f.name
+        try:
+            shard_dir = output_path
+            if gather and world > 1 and rank != 0:
+                shard_dir = tempfile.mkdtemp(prefix="zwz_shard_r%d_" % rank)
+            if rank < count_fn(local_record):                       # main.cpp:44-51
+                compress_fn(source_path, shard_dir, local_record, rank, world)
+            else:
+                print("Rank: %d - No file to compress" % rank, file=out)
+            if gather and world > 1:
+                path = os.path.join(shard_dir, "compressed_%d.zwz" % rank)
+                blob = open(path, "rb").read() if os.path.exists(path) else b""
+                blobs = gather_blobs(blob, 0)
+                if rank == 0:
+                    for r, b in enumerate(blobs):
+                        if r and b:
+                            with open(os.path.join(output_path, "compressed_%d.zwz" % r), "wb") as g:
+                                g.write(b)
+        finally:
+            os.unlink(local_record)
+    elif rank == 0:                                                  # main.cpp:61-68
+        if world > 1:
+            print("Decompression is not supported in MPI parallel mode.\nOnly use one process to decompress.", file=out)
+        decompress_fn(source_path, output_path)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:                                                    # main.cpp:148-155
+        print("========================================\nOperation: %s\nProcessor Count: %d\nTime Taken: %g seconds\n"
+              "========================================" % (operation, world, time.perf_counter() - start), file=out)
+    return rc
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="main", usage="%(prog)s <compress/decompress> <source directory path> <output directory path>")
+    ap.add_argument("operation")
+    ap.add_argument("source")
+    ap.add_argument("output")
+    ap.add_argument("--gather", action="store_true", help="collect every rank's shard on rank 0 (RCCL all_gather)")
+    args = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        dist = _dist()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl")
+        else:
+            dist.init_process_group("gloo")
+    try:
+        return run(args.operation, args.source, args.output, gather=args.gather)
+    finally:
+        if world > 1:
+            _dist().destroy_process_group()
+
+
+if __name__ == "__main__":
+    sys.exit(main())
