@@ -189,4 +189,46 @@ ZWZ_HD ParseResult lz_parse(EntryFn entries /* (p, which32) -> packed entry */, 
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block-parallel form of the walk (what the lz_parse kernel runs; the sequential lz_parse above is
+// its specification and both are diffed on the host by tests/).
+//
+// "Fresh" state at position q = nothing pending (zlib's prev_length == 2).  From a fresh q the
+// walk's next fresh position depends only on the records at q .. q+13:
+//   no e128 record at q        -> literal, next fresh = q + 1
+//   record of length b at q    -> lazy chain: while b < 16 and the record consulted at the next
+//                                 position (e32 if b >= 8 else e128) is longer, move on; the match
+//                                 emitted starts at m (q <= m <= q + 12), the positions q .. m-1
+//                                 are literals, next fresh = m + len.
+// Every position's transition is computed independently; the walk itself is then the orbit of
+// position 0 under "next fresh", found 64 positions at a time.
+struct FreshStep {
+    uint32_t next;      // next fresh position (q + 1 for a literal)
+    uint32_t mpos;      // start of the emitted match (unused for a literal)
+    uint32_t sel;       // 1 = the match is the e32 record of mpos
+    uint32_t is_lit;
+};
+
+template <class EntryFn>
+ZWZ_HD FreshStep fresh_step(EntryFn entries /* (p, sel) -> record, 0 beyond the chunk */, uint32_t q, uint32_t L) {
+    FreshStep r;
+    uint32_t e = entries(q, 0u);
+    if (e == 0) { r.next = q + 1; r.mpos = q; r.sel = 0; r.is_lit = 1; return r; }
+    uint32_t b = entry_len(e), m = q, sel = 0;
+    while (b < kMaxLazy && m + 1 < L) {
+        const uint32_t s2 = b >= kGoodLen ? 1u : 0u;
+        const uint32_t c = entries(m + 1, s2);
+        if (entry_len(c) <= b) break;
+        b = entry_len(c); sel = s2; m++;
+    }
+    r.next = m + b; r.mpos = m; r.sel = sel; r.is_lit = 0;
+    return r;
+}
+
+// Inclusive prefix XOR over the bits of a word: bit i of the result = XOR of bits 0..i.
+ZWZ_HD uint64_t prefix_xor64(uint64_t x) {
+    x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+    return x;
+}
+
 }  // namespace zwz

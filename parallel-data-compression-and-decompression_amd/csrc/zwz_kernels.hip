@@ -216,53 +216,134 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz_parse: the sequential lazy-match walk, one wave per chunk.  The walk itself is scalar (every
-// lane runs the same control flow on wave-uniform values); the wave exists to fetch the records:
-// 64 consecutive records per coalesced 512-byte load, the next window prefetched, lookups served
-// by v_readlane.  (One lane per chunk dragged the whole 8 B/position table through uncoalesced
-// loads: 139 ms for 50k text chunks.)
+// lz_parse: the lazy-match walk, one wave per chunk, 64 positions per step, no sequential walk:
+//   1. every lane computes the transition of "fresh at my position" (lz_core.h fresh_step);
+//   2. the walk's nodes inside the block are the orbit of the block's entry position under
+//      "next fresh": pointer doubling over 64 lanes, at most 6 rounds, early exit;
+//   3. the fresh lanes scatter bits into 8-word LDS rings (a jump reaches at most 5 blocks ahead):
+//      entry bit of a later block, match start, e32 selector, first interior position of the match;
+//   4. a position is covered by a match iff the latest event at or before it is an interior start
+//      (events: interior starts and fresh positions); symbols = the rest.
+// (A scalar walk cost ~150 vector instructions per symbol: 81 ms for 50k text chunks.)
+struct ParseWaveMem {
+    uint2 win[128];            // records of positions & 127 (this block and the next)
+    uint32_t ring_r[16], ring_s[16], ring_m[16], ring_m32[16];   // 8 x 64-bit words each, as halves
+    uint8_t flag[64];
+};
+
 __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n,
                                                                 const uint2* __restrict__ entries, const uint64_t* __restrict__ has128,
                                                                 uint64_t* __restrict__ sym, uint64_t* __restrict__ mst,
                                                                 uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info) {
+    __shared__ ParseWaveMem s_mem[kParseThreads / 64];
     const uint32_t chunk = blockIdx.x * (kParseThreads / 64) + (threadIdx.x >> 6);
     if (chunk >= n) return;
+    ParseWaveMem& m = s_mem[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     const uint2* ent = entries + (size_t)chunk * kEntryStride;
-    const uint32_t L = in_len[chunk];
-    uint32_t win = 0xffffffffu;             // first position of the window held in `cur`
-    uint32_t cx = 0, cy = 0, nx = 0, ny = 0;   // current / prefetched window: e128 in x, e32 in y
-    uint64_t cmask = 0, nmask = 0;             // has128 words of the current / prefetched window
     const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
-    auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t {
-        p = __builtin_amdgcn_readfirstlane(p);
-        sel = __builtin_amdgcn_readfirstlane(sel);
-        const uint32_t w = p & ~63u;
-        if (w != win) {                     // wave-uniform
-            // records exist only where lz_match found something: gate every lane on its has128 bit
-            if (w == win + 64u) { cx = nx; cy = ny; cmask = nmask; }
-            else { cmask = hm[w >> 6]; const uint2 e = ent[w + lane]; const bool on = (cmask >> lane) & 1ull; cx = on ? e.x : 0u; cy = on ? e.y : 0u; }
-            win = w;
-            if (w + 64u < kEntryStride) {   // rows are 65536 records long
-                nmask = hm[(w >> 6) + 1u];
-                const uint2 e = ent[w + 64u + lane]; const bool on = (nmask >> lane) & 1ull; nx = on ? e.x : 0u; ny = on ? e.y : 0u;
+    uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
+    uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
+    uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
+    const uint32_t L = in_len[chunk];
+    const uint32_t nwords = (L + 63) >> 6;
+
+    if (lane < 16) { m.ring_r[lane] = lane == 0 ? 1u : 0u; m.ring_s[lane] = 0; m.ring_m[lane] = 0; m.ring_m32[lane] = 0; }
+    // records exist only where lz_match found something: gate every lane on its has128 bit
+    uint64_t hw_pre = 0;                             // has128 word of the window in `pre`
+    auto fetch = [&](uint32_t w) -> uint2 {          // window w (64 records), zeros past the chunk
+        uint2 e = make_uint2(0u, 0u);
+        hw_pre = 0;
+        if (w < nwords) { hw_pre = hm[w]; if ((hw_pre >> lane) & 1ull) e = ent[(w << 6) + lane]; }
+        return e;
+    };
+    uint2 pre = fetch(0);
+    m.win[lane] = pre;
+    uint64_t hw_cur = hw_pre;                        // has128 word of the block being processed
+    pre = fetch(1);
+    uint32_t carry_open = 0, n_sym = 0, last_is_match = 0;
+    auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t { const uint2 e = m.win[p & 127u]; return sel ? e.y : e.x; };
+
+    for (uint32_t blk = 0; blk < nwords; blk++) {
+        const uint32_t base = blk << 6, q = base + lane;
+        m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2 in flight
+        const uint64_t hw_blk = hw_cur;
+        hw_cur = hw_pre;
+        pre = fetch(blk + 2);
+        const bool valid = q < L;
+        {   // literal-only block entered at its first position with nothing pending: no walk to do
+            const uint32_t slot = 2 * (blk & 7u);
+            const uint32_t quiet = (m.ring_r[slot] == 1u) & ((m.ring_r[slot + 1] | m.ring_s[slot] | m.ring_s[slot + 1] |
+                                                              m.ring_m[slot] | m.ring_m[slot + 1]) == 0u);
+            if (hw_blk == 0 && carry_open == 0 && __builtin_amdgcn_readfirstlane(quiet)) {
+                const uint64_t vm = __ballot(valid);
+                n_sym += (uint32_t)__popcll(vm);
+                if (lane == 0) {
+                    gsym[blk] = vm; gmst[blk] = 0; gm32[blk] = 0;
+                    m.ring_r[slot] = 0;
+                    if (base + 64u < L) m.ring_r[2 * ((blk + 1u) & 7u)] |= 1u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                continue;
             }
         }
-        const uint32_t vx = __builtin_amdgcn_readlane(cx, p & 63u), vy = __builtin_amdgcn_readlane(cy, p & 63u);
-        return sel ? vy : vx;
-    };
-    // the mask word of the window in registers comes from a ballot; skipping ahead over literal
-    // runs reads lz_match's has128 words instead of whole record windows
-    auto has = [&](uint32_t wi) -> uint64_t {
-        wi = __builtin_amdgcn_readfirstlane(wi);
-        return (wi << 6) == win ? cmask : hm[wi];
-    };
-    ParseResult r = lz_parse(lookup, has, L, sym + (size_t)chunk * kMaskWords,
-                             mst + (size_t)chunk * kMaskWords, m32 + (size_t)chunk * kMaskWords);
+        m.flag[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        FreshStep st{q + 1, q, 0u, 1u};
+        if (valid) st = fresh_step(lookup, q, L);
+        uint32_t succ = st.next >= base + 64u ? 64u : st.next - base;      // 64 = leaves the block
+        const uint64_t entry = ((uint64_t)m.ring_r[2 * (blk & 7u)] | ((uint64_t)m.ring_r[2 * (blk & 7u) + 1] << 32));
+        const uint64_t validm = __ballot(valid);
+        uint64_t marks = entry & validm;
+        if (marks) {
+            const uint64_t nonlit = __ballot(valid && !st.is_lit);
+            const uint32_t e0 = (uint32_t)__builtin_ctzll(marks);
+            if ((nonlit >> e0) == 0) {
+                marks = validm & ~((1ull << e0) - 1ull);                 // only literals from the entry on
+            } else {
+                for (uint32_t round = 0; round < 6; round++) {
+                    if (((marks >> lane) & 1ull) && succ < 64u) m.flag[succ] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const uint64_t now = marks | __ballot(m.flag[lane] != 0);
+                    const uint32_t s2 = __shfl(succ, succ & 63u);
+                    succ = succ < 64u ? s2 : 64u;
+                    if (now == marks) break;                             // orbit complete
+                    marks = now;
+                }
+                marks &= validm;
+            }
+        }
+        const bool fresh = (marks >> lane) & 1ull;
+        if (fresh) {
+            const uint32_t nx = st.next;
+            if (nx >= base + 64u && nx < L) atomicOr(&m.ring_r[((nx >> 5) & 15u)], 1u << (nx & 31u));
+            if (!st.is_lit) {
+                const uint32_t mp = st.mpos, sp = st.mpos + 1u;
+                atomicOr(&m.ring_m[(mp >> 5) & 15u], 1u << (mp & 31u));
+                if (st.sel) atomicOr(&m.ring_m32[(mp >> 5) & 15u], 1u << (mp & 31u));
+                atomicOr(&m.ring_s[(sp >> 5) & 15u], 1u << (sp & 31u));
+            }
+        }
+        last_is_match |= (uint32_t)(__ballot(fresh && !st.is_lit && st.next == L) != 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t slot = 2 * (blk & 7u);
+        const uint64_t S = (uint64_t)m.ring_s[slot] | ((uint64_t)m.ring_s[slot + 1] << 32);
+        const uint64_t M = (uint64_t)m.ring_m[slot] | ((uint64_t)m.ring_m[slot + 1] << 32);
+        const uint64_t M32 = (uint64_t)m.ring_m32[slot] | ((uint64_t)m.ring_m32[slot + 1] << 32);
+        const uint64_t X = S | marks;
+        const uint64_t upto = X & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const bool open = upto ? ((S >> (63u - (uint32_t)__builtin_clzll(upto))) & 1ull) : (carry_open != 0);
+        const uint64_t cover = __ballot(open);
+        carry_open = (uint32_t)(cover >> 63);
+        const uint64_t sym_w = ~cover & validm;
+        n_sym += (uint32_t)__popcll(sym_w);
+        if (lane == 0) { gsym[blk] = sym_w; gmst[blk] = M; gm32[blk] = M32; }
+        if (lane < 2) { m.ring_r[slot + lane] = 0; m.ring_s[slot + lane] = 0; m.ring_m[slot + lane] = 0; m.ring_m32[slot + lane] = 0; }
+    }
     if (lane == 0) {
         ChunkInfo ci;
-        ci.n_sym = r.n_sym;
-        const uint32_t s_in = (r.n_sym > 0 && !r.last_is_match) ? r.n_sym - 1 : r.n_sym;
+        ci.n_sym = n_sym;
+        const uint32_t s_in = (n_sym > 0 && !last_is_match) ? n_sym - 1 : n_sym;
         ci.n_blocks = s_in / kSymsPerBlock + 1;
         info[chunk] = ci;
     }

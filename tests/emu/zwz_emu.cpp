@@ -175,3 +175,71 @@ extern "C" uint32_t emu_inflate(const uint8_t* in, uint32_t n, uint8_t* out, uin
     *status = st.status;
     return st.out_pos;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Lane-emulated block-parallel parse (mirrors the lz_parse kernel step by step: per 64-position
+// block, transitions -> orbit marking by pointer doubling -> bit scatter into 8-word rings ->
+// cover = "latest event at or before i is a match-interior start").  Returns 0 if its masks and
+// counters equal the sequential walk's.
+extern "C" int emu_parse_blocks_check(const uint8_t* in, uint32_t L) {
+    std::vector<uint8_t> data(L + 16, 0);
+    if (L) memcpy(data.data(), in, L);
+    std::vector<uint16_t> link(L + 1, 0), head(32768, 0);
+    for (uint32_t p = 0; p + 3 <= L; p++) { uint32_t h = hash3(data[p], data[p + 1], data[p + 2]); link[p] = head[h]; head[h] = (uint16_t)p; }
+    std::vector<uint32_t> e128(L + 64, 0), e32(L + 64, 0);
+    const uint32_t nwords = (L + 63) / 64;
+    std::vector<uint64_t> has(nwords + 1, 0), sym(nwords + 1, 0), mst(nwords + 1, 0), m32(nwords + 1, 0);
+    for (uint32_t p = 0; p < L; p++) { lz_search(data.data(), link.data(), 0, p, L, e128[p], e32[p]); if (e128[p]) has[p >> 6] |= 1ull << (p & 63); }
+    auto ent = [&](uint32_t p, uint32_t sel) { return p < L ? (sel ? e32[p] : e128[p]) : 0u; };
+    ParseResult ref = lz_parse(ent, [&](uint32_t wi) { return has[wi]; }, L, sym.data(), mst.data(), m32.data());
+
+    uint64_t ringR[8] = {0}, ringS[8] = {0}, ringM[8] = {0}, ringM32[8] = {0};
+    ringR[0] = 1;                       // position 0 is fresh
+    uint32_t carry_open = 0, n_sym = 0, last_is_match = 0;
+    for (uint32_t blk = 0; blk < nwords; blk++) {
+        const uint32_t base = blk * 64;
+        FreshStep st[64];
+        uint64_t valid = 0;
+        uint32_t succ[64];
+        for (uint32_t i = 0; i < 64; i++) {
+            const uint32_t q = base + i;
+            st[i] = FreshStep{q + 1, q, 0, 1};
+            if (q < L) { valid |= 1ull << i; st[i] = fresh_step(ent, q, L); }
+            succ[i] = st[i].next >= base + 64 ? 64u : st[i].next - base;       // 64 = leaves the block
+        }
+        uint64_t marks = ringR[blk & 7] & valid;                                // at most one entry bit
+        for (int round = 0; round < 6; round++) {                               // orbit of the entry, 2^round hops per round
+            uint64_t add = 0;
+            for (uint32_t i = 0; i < 64; i++) if (((marks >> i) & 1) && succ[i] < 64) add |= 1ull << succ[i];
+            marks |= add;
+            uint32_t s2[64];
+            for (uint32_t i = 0; i < 64; i++) s2[i] = succ[i] < 64 ? succ[succ[i]] : 64u;
+            memcpy(succ, s2, sizeof succ);
+        }
+        marks &= valid;
+        for (uint32_t i = 0; i < 64; i++) {                                     // scatter by the fresh lanes
+            if (!((marks >> i) & 1)) continue;
+            const FreshStep& f = st[i];
+            if (f.next >= base + 64 && f.next < L) ringR[(f.next >> 6) & 7] |= 1ull << (f.next & 63);
+            if (f.is_lit) continue;
+            if (f.next == L) last_is_match = 1;
+            ringM[(f.mpos >> 6) & 7] |= 1ull << (f.mpos & 63);
+            if (f.sel) ringM32[(f.mpos >> 6) & 7] |= 1ull << (f.mpos & 63);
+            ringS[((f.mpos + 1) >> 6) & 7] |= 1ull << ((f.mpos + 1) & 63);
+        }
+        const uint64_t S = ringS[blk & 7], X = S | marks;
+        uint64_t cover = 0;
+        for (uint32_t i = 0; i < 64; i++) {                                     // per lane: latest event at or before i
+            const uint64_t m = X & (i == 63 ? ~0ull : ((2ull << i) - 1));
+            const bool open = m ? ((S >> (63 - __builtin_clzll(m))) & 1) : carry_open;
+            if (open) cover |= 1ull << i;
+        }
+        carry_open = (uint32_t)((cover >> 63) & 1);
+        const uint64_t sym_w = ~cover & valid;
+        if (sym_w != sym[blk] || ringM[blk & 7] != mst[blk] || ringM32[blk & 7] != m32[blk]) return 2 + (int)blk;
+        n_sym += (uint32_t)__builtin_popcountll(sym_w);
+        ringR[blk & 7] = 0; ringS[blk & 7] = 0; ringM[blk & 7] = 0; ringM32[blk & 7] = 0;
+    }
+    if (n_sym != ref.n_sym || last_is_match != ref.last_is_match) return 1;
+    return 0;
+}

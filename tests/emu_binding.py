@@ -21,6 +21,8 @@ def load():
     lib.emu_inflate.restype = ctypes.c_uint32
     lib.emu_inflate.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
                                 ctypes.POINTER(ctypes.c_uint32)]
+    lib.emu_parse_blocks_check.restype = ctypes.c_int
+    lib.emu_parse_blocks_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
     return lib
 
 
