@@ -62,29 +62,29 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     const uint32_t nice = lookahead < kNiceLen ? lookahead : kNiceLen;
     const uint32_t limit = p > kMaxDist ? p - kMaxDist : 0;
     const uint32_t pp = p - org;
-    uint32_t best = kMinMatch - 1, best_pos = 0, n = 0, snap = 0;
+    uint32_t best = kMinMatch - 1, best_pos = 0, n = 0, snap = 0xffffffffu;
     uint32_t scan_w = load_u32(data, pp);                // scan[best-2 .. best+1]
-    bool have32 = false, go = true;
+    // Single-exit loop: a "nice" match ends the search by zeroing the next link, so the loop
+    // predicate is just (next > limit && n < 128) and the rare full comparison never touches control
+    // flow outside its own branch.  The snapshot after 32 candidates is a plain select; taking it
+    // right after a nice match is harmless (it then equals the final record, as zlib's would).
     do {
         const uint32_t c = cur - org;
         const uint32_t x = load_u32(data, c + best - 2u) ^ scan_w;
-        const uint32_t next = link[c];
-        bool nice_stop = false;
+        uint32_t next = link[c];
         if ((x & 0xffffffu) == 0) {                      // rare: worth a full comparison
-            uint32_t len = match_len_from(data, c, pp, 0u, max_len);
+            const uint32_t len = match_len_from(data, c, pp, 0u, max_len);
             if (len > best) {
                 best = len; best_pos = cur;
-                nice_stop = len >= nice;
-                if (!nice_stop) scan_w = load_u32(data, pp + best - 2u);
+                if (len >= nice) next = 0; else scan_w = load_u32(data, pp + best - 2u);
             }
         }
         n++;
-        if (n == kShortChain && !nice_stop) { have32 = true; snap = entry_pack(best, p - best_pos); }
+        if (n == kShortChain) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;
         cur = next;
-        go = !nice_stop && cur > limit && n < kMaxChain;
-    } while (go);
+    } while (cur > limit && n < kMaxChain);
     e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0;
-    e32 = have32 ? (entry_len(snap) >= kMinMatch ? snap : 0u) : e128;
+    e32 = snap != 0xffffffffu ? snap : e128;
     // TOO_FAR: a minimum-length match further than 4096 back is dropped (deflate_slow)
     if (entry_len(e128) == kMinMatch && entry_dist(e128) > kTooFar) e128 = 0;
     if (entry_len(e32) == kMinMatch && entry_dist(e32) > kTooFar) e32 = 0;
