@@ -64,11 +64,12 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     const uint32_t pp = p - org;
     uint32_t best = kMinMatch - 1, best_pos = 0, n = 0, snap = 0xffffffffu;
     uint32_t scan_w = load_u32(data, pp);                // scan[best-2 .. best+1]
-    // Single-exit loop: a "nice" match ends the search by zeroing the next link, so the loop
-    // predicate is just (next > limit && n < 128) and the rare full comparison never touches control
-    // flow outside its own branch.  The snapshot after 32 candidates is a plain select; taking it
-    // right after a nice match is harmless (it then equals the final record, as zlib's would).
-    do {
+    // Single-exit loops: a "nice" match ends the search by zeroing the next link, so each loop
+    // predicate is just (next > limit && n < bound) and the rare full comparison never touches
+    // control flow outside its own branch.  The walk is split at 32 candidates so that the snapshot
+    // zlib's short chain would return costs nothing per candidate (taking it right after a nice
+    // match is harmless: it then equals the final record).
+    auto examine = [&]() {
         const uint32_t c = cur - org;
         const uint32_t x = load_u32(data, c + best - 2u) ^ scan_w;
         uint32_t next = link[c];
@@ -80,9 +81,13 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
             }
         }
         n++;
-        if (n == kShortChain) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;
         cur = next;
-    } while (cur > limit && n < kMaxChain);
+    };
+    do examine(); while (cur > limit && n < kShortChain);
+    if (n == kShortChain) {
+        snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;
+        while (cur > limit && n < kMaxChain) examine();
+    }
     e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0;
     e32 = snap != 0xffffffffu ? snap : e128;
     // TOO_FAR: a minimum-length match further than 4096 back is dropped (deflate_slow)
