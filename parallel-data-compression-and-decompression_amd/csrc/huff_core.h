@@ -319,4 +319,11 @@ ZWZ_HD void symbol_bits(const uint16_t* lcode, const uint8_t* llen, const uint16
     bits = v; nbits = n;
 }
 
+// Code length only (first pass of the encoder's two-pass scan).
+ZWZ_HD uint32_t symbol_nbits(const uint8_t* llen, const uint8_t* dlen, uint32_t entry, uint32_t lit) {
+    if (entry == 0) return llen[lit];
+    const uint32_t c = length_code(entry_len(entry) - kMinMatch), d = dist_code(entry_dist(entry) - 1u);
+    return llen[257u + c] + length_extra_bits(c) + dlen[d] + dist_extra_bits(d);
+}
+
 }  // namespace zwz

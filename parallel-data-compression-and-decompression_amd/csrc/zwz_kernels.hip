@@ -539,13 +539,13 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
     uint64_t* s_sym = reinterpret_cast<uint64_t*>(smem + kOutWords * 4);          // kMaskWords
-    uint32_t* s_rank = reinterpret_cast<uint32_t*>(s_sym + kMaskWords);           // kMaskWords
-    uint16_t* s_lcode = reinterpret_cast<uint16_t*>(s_rank + kMaskWords);         // kMaxBlocks * 288
+    uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_sym + kMaskWords);           // kMaskWords (symbols before word w < 65536)
+    uint16_t* s_lcode = s_rank + kMaskWords;                                      // kMaxBlocks * 288
     uint16_t* s_dcode = s_lcode + kMaxBlocks * 288;                               // kMaxBlocks * 32
     uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
     uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
     __shared__ EncBlock s_blk[kMaxBlocks];
-    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_wsum2[kEncodeThreads / 64];
+    __shared__ uint32_t s_wsum[kEncodeThreads / 64];
     __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
     __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
 
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         __syncthreads();
         uint32_t wbase = 0;
         for (uint32_t i = 0; i < (tid >> 6); i++) wbase += s_wsum[i];
-        s_rank[tid] = wbase + incl - cnt;
+        s_rank[tid] = (uint16_t)(wbase + incl - cnt);
     }
     for (uint32_t b = 0; b < ci.n_blocks; b++) {
         if (bo[b].type == kStored) continue;   // stored blocks carry no codes (plan may not have built any)
@@ -650,46 +650,78 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
             }
         }
     } else {
-    // symbols: one position per thread per step; exclusive scan of code lengths gives bit offsets
-    uint32_t carry = 0;        // symbol bits emitted before this step (all Huffman blocks)
-    for (uint32_t base = 0; base < (nwords << 6); base += kEncodeThreads) {
-        const uint32_t p = base + tid, wi = p >> 6, bit = p & 63;
-        uint64_t v = 0; uint32_t nb = 0, blk = 0;
-        bool is_sym = false;
-        uint32_t byte = 0;
-        if (p < L) {
-            byte = data[p];
-            a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
-            const uint64_t sw = s_sym[wi];
-            is_sym = (sw >> bit) & 1ull;
-            const uint32_t idx = s_rank[wi] + (uint32_t)__popcll(sw & ((1ull << bit) - 1ull));
-            blk = idx / kSymsPerBlock; if (blk >= ci.n_blocks) blk = ci.n_blocks - 1;
-            // a covered position belongs to the block of the symbol that covers it: rank counts
-            // symbols starting before p, so idx-1 is that symbol
-            if (!is_sym) { blk = (idx - 1) / kSymsPerBlock; if (blk >= ci.n_blocks) blk = ci.n_blocks - 1; }
-            if (s_blk[blk].type == kStored) {
-                const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
-                if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
-            } else if (is_sym) {
-                uint32_t e = 0;
-                if ((gmst[wi] >> bit) & 1ull) { const uint2 e2 = ent[p]; e = ((gm32[wi] >> bit) & 1ull) ? e2.y : e2.x; }
-                symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, e, byte, v, nb);
+        // Symbols.  Wave w owns the contiguous positions [4096 w, 4096 w + 4096): a first pass adds up
+        // its code lengths, one barrier turns the 16 wave totals into start offsets, and the second
+        // pass packs bits with wave-local scans only (a barrier per 1024 positions kept the single
+        // resident workgroup of a CU waiting: 30 ms for 50k text chunks).
+        const uint32_t wave = tid >> 6, lane = lane_id();
+        const uint32_t seg = wave * 4096u, seg_end = min(seg + 4096u, L);
+        // blocks are contiguous position ranges: a position's block is the number of block starts at
+        // or before it (holds for covered positions too: a block ends where its last symbol ends)
+        const uint32_t b1 = ci.n_blocks > 1 ? s_blk[1].start : 0xffffffffu, b2 = ci.n_blocks > 2 ? s_blk[2].start : 0xffffffffu;
+        const uint32_t b3 = ci.n_blocks > 3 ? s_blk[3].start : 0xffffffffu, b4 = ci.n_blocks > 4 ? s_blk[4].start : 0xffffffffu;
+        // The segment's 64 words of the match / selector masks sit one per lane and are handed out by
+        // v_readlane; each trip's byte and match record are fetched one trip ahead (the loop was
+        // bound by a global-load round trip per trip).
+        const uint32_t w0 = seg >> 6;
+        const uint64_t mst_l = (w0 + lane < nwords) ? gmst[w0 + lane] : 0ull;
+        const uint64_t m32_l = (w0 + lane < nwords) ? gm32[w0 + lane] : 0ull;
+        auto word_of = [&](uint64_t v, uint32_t it) -> uint64_t {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, it);          // the builtin returns int:
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), it);  // widen only after the cast
+            return (uint64_t)lo | ((uint64_t)hi << 32);
+        };
+        auto fetch = [&](uint32_t it, uint32_t& byte, uint32_t& e) {   // trip `it` of this wave's segment
+            byte = 0; e = 0;
+            if (it >= 64u) return;                                     // wave-uniform
+            const uint64_t mw = word_of(mst_l, it), sw = word_of(m32_l, it);   // readlane outside divergent code
+            const uint32_t p = seg + (it << 6) + lane;
+            if (p < seg_end) {
+                byte = data[p];
+                if ((mw >> lane) & 1ull) { const uint2 e2 = ent[p]; e = ((sw >> lane) & 1ull) ? e2.y : e2.x; }
+            }
+        };
+        auto block_of = [&](uint32_t p) { return (uint32_t)(p >= b1) + (uint32_t)(p >= b2) + (uint32_t)(p >= b3) + (uint32_t)(p >= b4); };
+        const uint32_t trips = (seg_end > seg ? seg_end - seg + 63u : 0u) >> 6;
+
+        uint32_t mine = 0, byte_n, e_n;
+        fetch(0, byte_n, e_n);
+        for (uint32_t it = 0; it < trips; it++) {
+            const uint32_t p = seg + (it << 6) + lane, byte = byte_n, e = e_n;
+            fetch(it + 1, byte_n, e_n);
+            if (p < seg_end && ((s_sym[p >> 6] >> lane) & 1ull)) {
+                const uint32_t blk = block_of(p);
+                if (s_blk[blk].type != kStored) mine += symbol_nbits(s_llen + blk * 288, s_dlen + blk * 32, e, byte);
             }
         }
-        uint32_t incl = nb;
-        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane_id() >= d) incl += t; }
-        uint32_t* ws = (base / kEncodeThreads) & 1 ? s_wsum2 : s_wsum;   // double buffer: one barrier per step
-        if (lane_id() == 63) ws[tid >> 6] = incl;
+        for (uint32_t d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        if (lane == 0) s_wsum[wave] = mine;
         __syncthreads();
-        uint32_t wbase = 0, total = 0;
-        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { uint32_t s = ws[i]; if (i < (tid >> 6)) wbase += s; total += s; }
-        if (nb) {
-            const uint32_t before = carry + wbase + incl - nb;   // symbol bits before this symbol
-            const EncBlock& e = s_blk[blk];
-            lds_or_bits(s_out, (uint64_t)e.body_pos + (before - e.sym_bits_before), v, nb);
+        uint32_t running = 0;      // symbol bits emitted before this wave's segment (all Huffman blocks)
+        for (uint32_t i = 0; i < wave; i++) running += s_wsum[i];
+        fetch(0, byte_n, e_n);
+        for (uint32_t it = 0; it < trips; it++) {
+            const uint32_t p = seg + (it << 6) + lane, byte = byte_n, e = e_n;
+            fetch(it + 1, byte_n, e_n);
+            uint64_t v = 0; uint32_t nb = 0, blk = 0;
+            if (p < seg_end) {
+                blk = block_of(p);
+                a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
+                if (s_blk[blk].type == kStored) {
+                    const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
+                    if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
+                } else if ((s_sym[p >> 6] >> lane) & 1ull) {
+                    symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, e, byte, v, nb);
+                }
+            }
+            uint32_t incl = nb;
+            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            if (nb) {
+                const EncBlock& eb = s_blk[blk];
+                lds_or_bits(s_out, (uint64_t)eb.body_pos + (running + incl - nb - eb.sym_bits_before), v, nb);
+            }
+            running += __shfl(incl, 63);
         }
-        carry += total;
-    }
     }
 
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
