@@ -413,20 +413,40 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
     // histograms, position-parallel (coalesced byte / record reads)
     const uint8_t* data = in + in_off[chunk];
     const uint2* ent = entries + (size_t)chunk * kEntryStride;
-    for (uint32_t p = tid; p < (nwords << 6); p += kBlockifyThreads) {
-        const uint32_t wi = p >> 6, bit = p & 63;
-        const uint64_t sw = s_sym[wi];
-        if (!((sw >> bit) & 1ull)) continue;
-        const uint32_t idx = s_rank[wi] + (uint32_t)__popcll(sw & ((1ull << bit) - 1ull));
-        uint32_t b = idx / kSymsPerBlock;
-        if (b >= ci.n_blocks) b = ci.n_blocks - 1;
-        if ((gmst[wi] >> bit) & 1ull) {
-            const uint2 e2 = ent[p];
-            const uint32_t e = ((gm32[wi] >> bit) & 1ull) ? e2.y : e2.x;
-            atomicAdd(&s_hist[b][257u + length_code(entry_len(e) - kMinMatch)], 1u);
-            atomicAdd(&s_hist[b][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
-        } else {
-            atomicAdd(&s_hist[b][data[p]], 1u);
+    // four positions per thread per trip, all loads of a trip issued before the first use (one
+    // position per trip left the loop waiting out a global-load round trip each time); a position's
+    // block is the number of block starts at or before it
+    const uint32_t c1 = ci.n_blocks > 1 ? s_start[1] : 0xffffffffu, c2 = ci.n_blocks > 2 ? s_start[2] : 0xffffffffu;
+    const uint32_t c3 = ci.n_blocks > 3 ? s_start[3] : 0xffffffffu, c4 = ci.n_blocks > 4 ? s_start[4] : 0xffffffffu;
+    for (uint32_t p0 = tid; p0 < (nwords << 6); p0 += 4 * kBlockifyThreads) {
+        uint32_t byte[4]; uint64_t mw[4], sw3[4]; uint2 e2[4]; bool isym[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t p = p0 + u * kBlockifyThreads, wi = p >> 6;
+            const bool in = wi < nwords;
+            isym[u] = in && ((s_sym[in ? wi : 0] >> (p & 63)) & 1ull);
+            byte[u] = (in && p < L) ? data[p] : 0u;
+            mw[u] = in ? gmst[wi] : 0ull;
+            sw3[u] = in ? gm32[wi] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t p = p0 + u * kBlockifyThreads;
+            e2[u] = make_uint2(0u, 0u);
+            if (isym[u] && ((mw[u] >> (p & 63)) & 1ull)) e2[u] = ent[p];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (!isym[u]) continue;
+            const uint32_t p = p0 + u * kBlockifyThreads, bit = p & 63;
+            const uint32_t bk = (uint32_t)(p >= c1) + (uint32_t)(p >= c2) + (uint32_t)(p >= c3) + (uint32_t)(p >= c4);
+            if ((mw[u] >> bit) & 1ull) {
+                const uint32_t e = ((sw3[u] >> bit) & 1ull) ? e2[u].y : e2[u].x;
+                atomicAdd(&s_hist[bk][257u + length_code(entry_len(e) - kMinMatch)], 1u);
+                atomicAdd(&s_hist[bk][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
+            } else {
+                atomicAdd(&s_hist[bk][byte[u]], 1u);
+            }
         }
     }
     __syncthreads();
