@@ -652,10 +652,17 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         // incompressible chunk: every block is a byte copy behind a 5-byte header; no code lengths,
         // no scan, no barriers -- four input bytes per thread per trip
         const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
-        for (uint32_t i = tid * 4u; i < L; i += kEncodeThreads * 4u) {
-            uint32_t w;
-            if (i + 4u <= ((L + 15u) & ~15u)) w = d32[i >> 2];   // slot readable to the next multiple of 16
-            else { w = 0; for (uint32_t j = 0; j < 4 && i + j < L; j++) w |= (uint32_t)data[i + j] << (8 * j); }
+        const uint32_t Lr = (L + 15u) & ~15u;                         // slot readable to the next multiple of 16
+        uint32_t w[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; u++) {                           // the chunk's 16 dwords of this thread, all in flight
+            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+            w[u] = i < Lr ? d32[i >> 2] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 16; u++) {
+            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+            if (i >= L) break;
             uint32_t blk = 0;
             while (blk + 1 < ci.n_blocks && i >= s_blk[blk].end) blk++;
 #pragma unroll
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
                 const uint32_t p = i + j;
                 if (p >= L) break;
                 if (p >= s_blk[blk].end) blk++;
-                const uint32_t byte = (w >> (8 * j)) & 0xffu;
+                const uint32_t byte = (w[u] >> (8 * j)) & 0xffu;
                 a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
                 const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
                 if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
