@@ -260,17 +260,23 @@ ZWZ_HD BlockPlan plan_block(TreeScratch& ts, const uint16_t* lfreq, const uint16
 // most 6 non-zero lengths).  Incompressible data clears the threshold by ~100 bits per block, so
 // the heap-built trees are only constructed for blocks that may really be Huffman coded.
 
-// Optimal prefix-code cost of ascending weights sorted[0..m) (two-queue merge).  queue: m words.
+// Optimal prefix-code cost of ascending weights sorted[0..m) (two-queue merge; queue: m + 2 words,
+// sorted: m + 2 entries readable).  The two smallest live items are always among the next two
+// leaves and the next two internal nodes, so each step reads those four at once (one LDS round
+// trip on the device) and decides in registers.
 ZWZ_HD uint32_t huffman_cost_sorted(const uint16_t* sorted, uint32_t m, uint32_t* queue) {
     if (m < 2) return 0;
+    constexpr uint32_t kInf = 0xffffffffu;
     uint32_t li = 0, qi = 0, qn = 0, cost = 0;
     for (uint32_t step = 1; step < m; step++) {
-        uint32_t pick[2];
-        for (int k = 0; k < 2; k++) {
-            const bool leaf = li < m && (qi >= qn || sorted[li] <= queue[qi]);
-            pick[k] = leaf ? sorted[li++] : queue[qi++];
+        const uint32_t l0 = li < m ? sorted[li] : kInf, l1 = li + 1 < m ? sorted[li + 1] : kInf;
+        const uint32_t q0 = qi < qn ? queue[qi] : kInf, q1 = qi + 1 < qn ? queue[qi + 1] : kInf;
+        uint32_t sum;
+        if (l0 <= q0) {
+            if (l1 <= q0) { sum = l0 + l1; li += 2; } else { sum = l0 + q0; li++; qi++; }
+        } else {
+            if (l0 <= q1) { sum = q0 + l0; li++; qi++; } else { sum = q0 + q1; qi += 2; }
         }
-        const uint32_t sum = pick[0] + pick[1];
         cost += sum;
         queue[qn++] = sum;
     }

@@ -266,6 +266,31 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
 
     for (uint32_t blk = 0; blk < nwords; blk++) {
         const uint32_t base = blk << 6, q = base + lane;
+        {   // run of literal-only blocks entered at a block start with nothing pending: settle up to 64
+            // blocks at once (incompressible data is almost all such runs)
+            const uint32_t slot = 2 * (blk & 7u);
+            const uint32_t quiet = (m.ring_r[slot] == 1u) & ((m.ring_r[slot + 1] | m.ring_s[slot] | m.ring_s[slot + 1] |
+                                                              m.ring_m[slot] | m.ring_m[slot + 1]) == 0u);
+            if (hw_cur == 0 && carry_open == 0 && __builtin_amdgcn_readfirstlane(quiet)) {
+                const uint32_t w = blk + lane;
+                const uint64_t word = w < nwords ? hm[w] : ~0ull;
+                const uint64_t zeros = __ballot(word == 0 && ((w + 1u) << 6) <= L);
+                const uint32_t run = zeros == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~zeros);
+                if (run >= 2u) {
+                    if (lane < run) { gsym[w] = ~0ull; gmst[w] = 0; gm32[w] = 0; }
+                    n_sym += 64u * run;
+                    const uint32_t nb = blk + run;
+                    if (lane == 0) { m.ring_r[slot] = 0; if ((nb << 6) < L) m.ring_r[2 * (nb & 7u)] |= 1u; }
+                    pre = fetch(nb);                 // re-prime the window pipeline at block nb
+                    m.win[((nb << 6) + lane) & 127u] = pre;
+                    hw_cur = hw_pre;
+                    pre = fetch(nb + 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    blk = nb - 1u;
+                    continue;
+                }
+            }
+        }
         m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2 in flight
         const uint64_t hw_blk = hw_cur;
         hw_cur = hw_pre;
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     __shared__ BlockCodes bc;
     __shared__ uint32_t hdr[kHdrWords];
     __shared__ uint16_t lf[kLCodes], df[kDCodes];
-    __shared__ uint16_t sorted[kLCodes];
+    __shared__ uint16_t sorted[kLCodes + 2];
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
     if (b >= info[chunk].n_blocks) return;
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
@@ -505,6 +530,18 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     uint32_t m_l = 0, m_d = 0, certain = 0;
     if (stored_ok && stored_len > 0) {
         uint32_t* queue = ts.heap;                      // scratch not yet in use
+        // exact static_len / extra bits / used codes: five symbols per lane, wave reduction
+        StoredProbe pr{0, 0, 0};
+        for (uint32_t n = threadIdx.x; n < kLCodes + kDCodes; n += 64) {
+            const bool lit = n < kLCodes;
+            const uint32_t f = lit ? lf[n] : df[n - kLCodes];
+            if (!f) continue;
+            const uint32_t x = lit ? (n >= 257u ? length_extra_bits(n - 257u) : 0u) : dist_extra_bits(n - kLCodes);
+            pr.static_len += f * ((lit ? static_lit_len(n) : 5u) + x); pr.extra_bits += f * x; pr.used++;
+        }
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            pr.static_len += __shfl_xor(pr.static_len, d); pr.extra_bits += __shfl_xor(pr.extra_bits, d); pr.used += __shfl_xor(pr.used, d);
+        }
         wave_rank_sort(lf, kLCodes, sorted, &m_l);
         __syncthreads();
         uint32_t hl = 0, hd = 0;
@@ -514,7 +551,6 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
         __syncthreads();
         if (threadIdx.x == 0) {
             hd = huffman_cost_sorted(sorted, m_d, queue);
-            const StoredProbe pr = probe_block(lf, df);
             certain = stored_is_certain(pr, hl, hd, stored_len, stored_ok) ? 1u : 0u;
         }
         certain = __builtin_amdgcn_readfirstlane(certain);
