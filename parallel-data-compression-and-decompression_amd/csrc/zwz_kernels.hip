@@ -819,7 +819,7 @@ struct InflateWaveMem {
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
-__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+__global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                   const uint32_t* __restrict__ in_len, uint32_t n,
                                                                   uint8_t* __restrict__ out, uint64_t out_stride,
                                                                   uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
