@@ -16,7 +16,7 @@ constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
 constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
-constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes;   // 147136 of 163840
+constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + 4096;   // + has128 bits + bucket counts: 153280 of 163840
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
@@ -49,6 +49,7 @@ struct DeflateArgs {
     uint8_t* out; uint64_t out_stride; uint32_t* out_len;                            // out_stride % 4 == 0, >= 65536
     // workspace (sized for n chunks)
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst; uint64_t* m32;
+    uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
 };
 
@@ -58,7 +59,7 @@ struct InflateArgs {
 };
 
 constexpr size_t kWorkspaceBytesPerChunk =
-    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 4 * (size_t)kMaskWords * 8 + sizeof(ChunkInfo) +
+    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 4 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + sizeof(ChunkInfo) +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
 
 hipError_t configure_kernels();

@@ -133,13 +133,18 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
 // spent 58% of its wave-cycles waiting on it).
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
-                                                                 uint2* __restrict__ entries, uint64_t* __restrict__ has128) {
+                                                                 uint2* __restrict__ entries, uint64_t* __restrict__ has128,
+                                                                 uint16_t* __restrict__ perms) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
     if (L == 0) return;
     uint8_t* sdata = smem;
     uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
+    uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // 2 KiB: has128 bits of a tile
+    uint16_t* s_cnt = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes + kMatchLinkBytes + 2048);   // 4 KiB: bucket counts
+    __shared__ uint32_t s_wtot[kMatchThreads / 64];
+    uint16_t* perm = perms + (size_t)chunk * kTile;
     uint4* sd4 = reinterpret_cast<uint4*>(sdata);
     uint4* sl4 = reinterpret_cast<uint4*>(slink);
     const uint4* gd4 = reinterpret_cast<const uint4*>(in + in_off[chunk]);                    // 16-byte aligned (API contract)
@@ -179,14 +184,82 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         __syncthreads();
         if (t + 1 < ntiles) ZWZ_PREFETCH(t + 1)     // in flight during the search below
 
-        const uint32_t tile_words_end = (te + 63u) & ~63u;
-        for (uint32_t p = ts + tid; p < tile_words_end; p += kMatchThreads) {
-            uint32_t e128 = 0, e32 = 0;
-            if (p < te) lz_search(sdata, slink, org, p, L, e128, e32);
-            if (e128) ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
-            const uint64_t m = __ballot(e128 != 0);
-            if (lane_id() == 0) hm[p >> 6] = m;
+        // Order of work inside the tile.  A wave finishes a trip when its longest chain does, and chain
+        // lengths run from 1 to 128 among neighbouring positions (21-29% VALU lane utilisation on
+        // text).  Positions with a similar distance to their second predecessor have similar chain
+        // lengths, so the tile is counting-sorted by an 8-bucket key of that distance and waves take 64
+        // positions of one bucket at a time (~0.58 utilisation, half the trips).  Tiles that look
+        // incompressible (few positions with two predecessors in range) keep the natural order.
+        const uint32_t npos = te - ts;
+        const uint32_t wave = tid >> 6, lane = lane_id();
+        auto key_of = [&](uint32_t p) -> uint32_t {
+            if (p >= te || p + kMinMatch > L) return 7u;
+            const uint32_t l1 = slink[p - org];
+            if (l1 == 0 || p - l1 > kMaxDist) return 7u;
+            const uint32_t l2 = slink[l1 - org];
+            if (l2 == 0 || p - l2 > kMaxDist) return 7u;
+            const uint32_t lg = 31u - (uint32_t)__builtin_clz(p - l2);
+            return (lg > 13u ? 13u : lg) >> 1;
+        };
+        for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of this tile (32-bit words)
+        const uint32_t sample = (uint32_t)__popcll(__ballot(key_of(ts + tid) < 7u));
+        if (lane == 0) s_cnt[wave] = (uint16_t)sample;
+        __syncthreads();
+        uint32_t chained = 0;
+        for (uint32_t i = 0; i < kMatchThreads / 64; i++) chained += s_cnt[i];
+        const bool sorted_order = chained * 2u >= min(npos, kMatchThreads);      // wave-uniform, workgroup-uniform
+        __syncthreads();
+        if (sorted_order) {
+            // counts[bucket][trip][wave] -> exclusive scan -> destination of every position
+            for (uint32_t kk = 0; kk < 16u; kk++) {
+                const uint32_t key = key_of(ts + tid + kk * kMatchThreads);
+                const bool in = tid + kk * kMatchThreads < npos;
+                uint32_t mycnt = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 8u; b++) { const uint32_t c = (uint32_t)__popcll(__ballot(in && key == b)); if (lane == b) mycnt = c; }
+                if (lane < 8u) s_cnt[(lane * 16u + kk) * 16u + wave] = (uint16_t)mycnt;
+            }
+            __syncthreads();
+            {   // exclusive scan of the 2048 counts, two per thread
+                const uint32_t a = s_cnt[2 * tid], bb = s_cnt[2 * tid + 1];
+                uint32_t incl = a + bb;
+                for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                if (lane == 63) s_wtot[wave] = incl;
+                __syncthreads();
+                uint32_t wbase = 0;
+                for (uint32_t i = 0; i < wave; i++) wbase += s_wtot[i];
+                const uint32_t ex = wbase + incl - a - bb;
+                s_cnt[2 * tid] = (uint16_t)ex; s_cnt[2 * tid + 1] = (uint16_t)(ex + a);
+            }
+            __syncthreads();
+            for (uint32_t kk = 0; kk < 16u; kk++) {
+                const uint32_t q = tid + kk * kMatchThreads;
+                const uint32_t key = key_of(ts + q);
+                const bool in = q < npos;
+                uint32_t rank = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 8u; b++) { const uint64_t mk = __ballot(in && key == b); if (key == b) rank = (uint32_t)__popcll(mk & lanes_below()); }
+                if (in) perm[(uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank] = (uint16_t)q;
+            }
+            __syncthreads();
         }
+        for (uint32_t kk = 0; kk < 16u; kk++) {
+            const uint32_t idx = tid + kk * kMatchThreads;
+            if (__ballot(idx < npos) == 0) break;
+            uint32_t e128 = 0, e32 = 0;
+            uint32_t p = 0;
+            if (idx < npos) {
+                p = ts + (sorted_order ? (uint32_t)perm[idx] : idx);
+                lz_search(sdata, slink, org, p, L, e128, e32);
+            }
+            if (e128) {
+                ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
+                atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads)
+            hm[(ts >> 6) + i] = (uint64_t)s_has[2 * i] | ((uint64_t)s_has[2 * i + 1] << 32);
         if (t + 1 == ntiles) break;
 
         // slide: the next tile starts at te and may look back 32506 positions
@@ -925,7 +998,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
-                       a.links, a.entries, a.has128);
+                       a.links, a.entries, a.has128, a.perm);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
