@@ -63,7 +63,11 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     const uint32_t limit = p > kMaxDist ? p - kMaxDist : 0;
     const uint32_t pp = p - org;
     uint32_t best = kMinMatch - 1, best_pos = 0, n = 0, snap = 0xffffffffu;
-    uint32_t scan_w = load_u32(data, pp);                // scan[best-2 .. best+1]
+    // filter word = the last bytes a longer match must share with the scan: bytes 0..2 while
+    // best == 2 (the trigram itself), bytes best-3..best afterwards (zlib's scan_end test widened
+    // to four bytes: fewer false hits, and a hit costs a full comparison)
+    uint32_t f_off = 0, f_mask = 0xffffffu;
+    uint32_t scan_w = load_u32(data, pp) & f_mask;
     // Single-exit loops: a "nice" match ends the search by zeroing the next link, so each loop
     // predicate is just (next > limit && n < bound) and the rare full comparison never touches
     // control flow outside its own branch.  The walk is split at 32 candidates so that the snapshot
@@ -71,13 +75,14 @@ ZWZ_HD void lz_search(const uint8_t* data, const uint16_t* link, uint32_t org, u
     // match is harmless: it then equals the final record).
     auto examine = [&]() {
         const uint32_t c = cur - org;
-        const uint32_t x = load_u32(data, c + best - 2u) ^ scan_w;
+        const uint32_t x = (load_u32(data, c + f_off) & f_mask) ^ scan_w;
         uint32_t next = link[c];
-        if ((x & 0xffffffu) == 0) {                      // rare: worth a full comparison
+        if (x == 0) {                                    // rare: worth a full comparison
             const uint32_t len = match_len_from(data, c, pp, 0u, max_len);
             if (len > best) {
                 best = len; best_pos = cur;
-                if (len >= nice) next = 0; else scan_w = load_u32(data, pp + best - 2u);
+                if (len >= nice) next = 0;
+                else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); }
             }
         }
         n++;
