@@ -68,7 +68,6 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
     c->max_batch = max_batch ? max_batch : 8192u;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = configure_kernels();
-    if (e == hipSuccess) e = hipMalloc(&c->workspace, (size_t)c->max_batch * kWorkspaceBytesPerChunk + 4096);
     for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
     if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create"); zwz_ctx_destroy(c); return rc; }
@@ -115,6 +114,16 @@ int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
     if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len))) return ZWZ_E_INVALID;
     if (out_stride < ZWZ_DEV_STRIDE || (out_stride & 15u) || ((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZWZ_E_INVALID;
     HIPCHK(hipSetDevice(c->device));
+    {   // the workspace grows to the largest slice seen (never past max_batch): small jobs and pure
+        // decompression never pay for the full ~5.6 GB
+        const uint32_t want = n < c->max_batch ? n : c->max_batch;
+        if (want > c->ws_chunks) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->workspace) { (void)hipFree(c->workspace); c->workspace = nullptr; c->ws_chunks = 0; }
+            HIPCHK(hipMalloc(&c->workspace, (size_t)want * kWorkspaceBytesPerChunk + 4096));
+            c->ws_chunks = want;
+        }
+    }
     for (uint32_t done = 0; done < n; done += c->max_batch) {
         const uint32_t m = n - done < c->max_batch ? n - done : c->max_batch;
         DeflateArgs a;
@@ -226,7 +235,7 @@ namespace zwz {
 
 void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     uint8_t* p = static_cast<uint8_t*>(c->workspace);
-    const size_t n = c->max_batch;
+    const size_t n = c->ws_chunks;
     auto take = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     a.entries = reinterpret_cast<uint2*>(take(n * kEntryStride * sizeof(uint2)));
     a.links = reinterpret_cast<uint16_t*>(take(n * kLinkStride * sizeof(uint16_t)));

@@ -10,6 +10,7 @@ struct zwz_ctx {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     void* workspace = nullptr;
+    uint32_t ws_chunks = 0;          // chunks the workspace is currently sized for
     // staging for the host-buffer entry points and the directory pipeline
     void* d_stage = nullptr;
     void* h_stage = nullptr;

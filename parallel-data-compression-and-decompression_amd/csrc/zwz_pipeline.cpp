@@ -1,0 +1,504 @@
+// zwz_pipeline.cpp -- the reference's per-rank pipelines, rebuilt around the batch codec:
+//   producer() + ConcurrenceQueue<Chunk> + consumer() + data_writer()   (compression.cpp:24-148)
+//   decompress_zwz() + do_decompression()                                (decompression.cpp:45-178)
+//
+// The reference moves every chunk through a mutex queue as a 65.5 KB struct copy (twice), calls
+// zlib once per chunk on one thread and computes each file's MD5 inside the writer lock.  Here:
+//   * chunks are pread() straight into 65536-byte slots of a pinned staging buffer by a small
+//     thread pool (slot positions are known up front from the file sizes);
+//   * a slice of chunks costs one H2D, one kernel pipeline and one D2H on the context's stream;
+//   * slices are double-buffered: while the GPU works on slice s the pool reads slice s+1 and the
+//     caller's thread writes the records of slice s-1;
+//   * MD5 runs on the pool, off the critical path (a file that fits in one slice is hashed from the
+//     staging buffer right after it was read; larger files are re-read, like md5_of_file does).
+// Record order is the reference's: files in list order restricted to this rank, chunks ascending
+// (SURVEY.md Appendix A), so shards stay byte-identical.
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <filesystem>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "zwz_api_internal.h"
+#include "zwz_md5.h"
+
+namespace fs = std::filesystem;
+using namespace zwz;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+namespace {
+
+bool verbose() { static int v = getenv("ZWZ_VERBOSE") ? 1 : 0; return v != 0; }
+
+bool blank(const std::string& s) {
+    return std::all_of(s.begin(), s.end(), [](unsigned char ch) { return std::isspace(ch) != 0; });
+}
+
+// Fixed pool of host workers with countable task groups.
+class Pool {
+public:
+    struct Group { std::atomic<int> pending{0}; };
+    explicit Pool(unsigned n) {
+        for (unsigned i = 0; i < n; i++) workers_.emplace_back([this] { run(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void submit(Group& g, std::function<void()> fn) {
+        g.pending.fetch_add(1);
+        { std::lock_guard<std::mutex> l(m_); q_.push_back({&g, std::move(fn)}); }
+        cv_.notify_one();
+    }
+    void wait(Group& g) {
+        std::unique_lock<std::mutex> l(m_);
+        done_cv_.wait(l, [&] { return g.pending.load() == 0; });
+    }
+private:
+    struct Task { Group* g; std::function<void()> fn; };
+    void run() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                t = std::move(q_.front()); q_.pop_front();
+            }
+            t.fn();
+            if (t.g->pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> l(m_); done_cv_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::deque<Task> q_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_ = false;
+};
+
+unsigned host_threads() {
+    if (const char* v = getenv("ZWZ_HOST_THREADS")) return (unsigned)std::max(1, atoi(v));
+    unsigned hc = std::thread::hardware_concurrency();
+    return std::min(16u, std::max(2u, hc));
+}
+
+// Two staging slices (in / out slots, offsets, lengths, status), pinned on the host and mirrored on
+// the device; reuses the context's staging allocation.
+struct Slices {
+    uint32_t cap = 0;      // chunks per slice
+    uint8_t *h_in[2], *h_out[2], *d_in[2], *d_out[2];
+    uint64_t *h_off[2], *d_off[2];
+    uint32_t *h_len[2], *h_olen[2], *h_st[2], *d_len[2], *d_olen[2], *d_st[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+};
+
+int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
+    int rc = ensure_staging(c, 2 * cap);
+    if (rc) return rc;
+    s.cap = cap;
+    auto carve = [&](uint8_t* base, int i, uint8_t*& in, uint8_t*& out, uint64_t*& off, uint32_t*& len, uint32_t*& olen, uint32_t*& st) {
+        const size_t total = c->stage_chunks;           // layout of stage_view(): [in | out | off | len | olen | st]
+        uint8_t* in0 = base; uint8_t* out0 = in0 + total * ZWZ_DEV_STRIDE;
+        uint64_t* off0 = reinterpret_cast<uint64_t*>(out0 + total * ZWZ_DEV_STRIDE);
+        uint32_t* len0 = reinterpret_cast<uint32_t*>(off0 + total); uint32_t* olen0 = len0 + total; uint32_t* st0 = olen0 + total;
+        const size_t o = (size_t)i * cap;
+        in = in0 + o * ZWZ_DEV_STRIDE; out = out0 + o * ZWZ_DEV_STRIDE; off = off0 + o; len = len0 + o; olen = olen0 + o; st = st0 + o;
+    };
+    for (int i = 0; i < 2; i++) {
+        carve(static_cast<uint8_t*>(c->h_stage), i, s.h_in[i], s.h_out[i], s.h_off[i], s.h_len[i], s.h_olen[i], s.h_st[i]);
+        carve(static_cast<uint8_t*>(c->d_stage), i, s.d_in[i], s.d_out[i], s.d_off[i], s.d_len[i], s.d_olen[i], s.d_st[i]);
+        hipError_t e = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    return ZWZ_OK;
+}
+
+void free_slices(Slices& s) { for (auto& e : s.done) if (e) (void)hipEventDestroy(e); }
+
+}  // namespace
+
+extern "C" {
+
+int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const char* file_record, int rank, int nranks) {
+    if (!c || !src_dir || !dst_dir || !file_record || rank < 0 || nranks <= 0) return ZWZ_E_INVALID;
+    std::vector<std::string> lines;
+    {
+        std::ifstream f(file_record);
+        if (!f.is_open()) { set_error("cannot open file record %s", file_record); return ZWZ_E_IO; }
+        std::string s;
+        while (std::getline(f, s)) lines.push_back(s);
+    }
+    int non_empty = 0;
+    for (const auto& s : lines) if (!s.empty() && !blank(s)) non_empty++;
+    if (rank >= non_empty) return ZWZ_OK;   // main.cpp:47-51: this rank has nothing to do and creates no shard
+
+    // this rank's files (compression.cpp:35-41); a file that cannot be opened is logged and skipped (:45-48)
+    struct File { std::string rel, full; int fd; uint64_t size; uint32_t first_chunk, nchunks; std::string md5; std::atomic<int>* md5_ready; };
+    std::vector<File> files;
+    uint64_t total_chunks = 0;
+    for (size_t i = (size_t)rank; i < lines.size(); i += (size_t)nranks) {
+        File f;
+        f.rel = lines[i];
+        f.full = (fs::path(src_dir) / f.rel).string();
+        f.fd = open(f.full.c_str(), O_RDONLY);
+        if (f.fd < 0) { fprintf(stderr, "Error opening source file: \"%s\"\n", f.full.c_str()); continue; }
+        struct stat sb;
+        fstat(f.fd, &sb);
+        f.size = (uint64_t)sb.st_size;
+        f.nchunks = (uint32_t)(f.size / ZWZ_CHUNK_SIZE) + 1;   // a short (possibly empty) read ends the file (:52-58)
+        f.first_chunk = (uint32_t)total_chunks;
+        f.md5_ready = nullptr;
+        total_chunks += f.nchunks;
+        files.push_back(std::move(f));
+    }
+    if (total_chunks > 0xffffffffull) { set_error("too many chunks"); return ZWZ_E_INVALID; }
+    std::vector<std::atomic<int>> ready(files.size());
+    for (size_t i = 0; i < files.size(); i++) { ready[i].store(0); files[i].md5_ready = &ready[i]; }
+
+    const std::string out_path = (fs::path(dst_dir) / ("compressed_" + std::to_string(rank) + ".zwz")).string();
+    FILE* dest = fopen(out_path.c_str(), "wb");
+    if (!dest) { for (auto& f : files) close(f.fd); set_error("cannot create %s", out_path.c_str()); return ZWZ_E_IO; }
+    std::vector<char> iobuf(16 << 20);
+    setvbuf(dest, iobuf.data(), _IOFBF, iobuf.size());
+
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t T = (uint32_t)total_chunks;
+    const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(4096u, (T + 1) / 2 + 1)));
+    Slices sl;
+    int rc = make_slices(c, cap, sl);
+    if (rc) { fclose(dest); for (auto& f : files) close(f.fd); return rc; }
+    const uint32_t nslices = (T + cap - 1) / cap;
+
+    Pool pool(host_threads());
+    Pool::Group md5_group, read_group[2];
+    // chunk g -> (file, chunk index in file): files are laid out back to back
+    auto file_of = [&](uint32_t g) -> uint32_t {
+        uint32_t lo = 0, hi = (uint32_t)files.size() - 1;
+        while (lo < hi) { uint32_t mid = (lo + hi + 1) / 2; if (files[mid].first_chunk <= g) lo = mid; else hi = mid - 1; }
+        return lo;
+    };
+    std::atomic<int> io_error{0};
+    auto hash_whole_file = [&](uint32_t fi) {     // md5_of_file(): re-read (verification.cpp:6-30)
+        Md5 m;
+        std::vector<uint8_t> buf(1 << 20);
+        uint64_t off = 0;
+        for (;;) {
+            ssize_t k = pread(files[fi].fd, buf.data(), buf.size(), (off_t)off);
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) break;
+            m.update(buf.data(), (size_t)k); off += (uint64_t)k;
+        }
+        char hex[33]; m.hex(hex);
+        files[fi].md5 = hex; files[fi].md5_ready->store(1);
+    };
+    auto start_read = [&](uint32_t s) {
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        uint32_t g = g0;
+        while (g < g1) {
+            const uint32_t fi = file_of(g);
+            const File& f = files[fi];
+            const uint32_t c0 = g - f.first_chunk, c1 = std::min(f.nchunks, c0 + (g1 - g));
+            const bool whole = c0 == 0 && c1 == f.nchunks;
+            if (!whole && c0 == 0) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });
+            // units of <= 64 chunks so that big files are read by several workers
+            for (uint32_t u0 = c0; u0 < c1; u0 += 64) {
+                const uint32_t u1 = std::min(c1, u0 + 64);
+                const bool hash_here = whole && u0 == 0 && u1 == c1;
+                pool.submit(read_group[b], [&, fi, b, g0, u0, u1, hash_here] {
+                    const File& ff = files[fi];
+                    Md5 m;
+                    for (uint32_t ci = u0; ci < u1; ci++) {
+                        const uint32_t slot = ff.first_chunk + ci - g0;
+                        uint8_t* dstp = sl.h_in[b] + (size_t)slot * ZWZ_DEV_STRIDE;
+                        const uint64_t off = (uint64_t)ci * ZWZ_CHUNK_SIZE;
+                        const size_t want = off < ff.size ? (size_t)std::min<uint64_t>(ZWZ_CHUNK_SIZE, ff.size - off) : 0;
+                        size_t got = 0;
+                        while (got < want) {
+                            ssize_t k = pread(ff.fd, dstp + got, want - got, (off_t)(off + got));
+                            if (k < 0 && errno == EINTR) continue;
+                            if (k <= 0) break;
+                            got += (size_t)k;
+                        }
+                        if (got != want) io_error.store(1);       // the file shrank under us
+                        sl.h_off[b][slot] = (uint64_t)slot * ZWZ_DEV_STRIDE;
+                        sl.h_len[b][slot] = (uint32_t)got;
+                        if (hash_here) m.update(dstp, got);
+                    }
+                    if (hash_here) { char hex[33]; m.hex(hex); files[fi].md5 = hex; files[fi].md5_ready->store(1); }
+                });
+            }
+            if (whole && c1 - c0 > 64) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });   // read in pieces: hash separately
+            g += c1 - c0;
+        }
+    };
+    // a whole file read as ONE unit is hashed by its reader; every other file by hash_whole_file
+    auto launch_gpu = [&](uint32_t s) -> int {
+        const int b = (int)(s & 1u);
+        const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
+        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        // offsets are relative to this slice's d_in
+        int r = zwz_deflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b]);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(sl.done[b], c->stream));
+        return ZWZ_OK;
+    };
+    uint32_t truncated = 0;
+    auto write_records = [&](uint32_t s) {       // data_writer(), compression.cpp:73-104
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        uint32_t fi = file_of(g0);
+        for (uint32_t g = g0; g < g1; g++) {
+            while (g >= files[fi].first_chunk + files[fi].nchunks) fi++;
+            const File& f = files[fi];
+            const uint32_t slot = g - g0;
+            const int32_t seq = (int32_t)(g - f.first_chunk);
+            const uint8_t last = seq + 1 == (int32_t)f.nchunks;
+            const int32_t path_len = (int32_t)f.rel.size(), payload = (int32_t)sl.h_olen[b][slot];
+            const int32_t total = 4 + path_len + 4 + 1 + payload;
+            fwrite(&total, 4, 1, dest);
+            fwrite(&path_len, 4, 1, dest);
+            fwrite(f.rel.data(), 1, (size_t)path_len, dest);
+            fwrite(&seq, 4, 1, dest);
+            fwrite(&last, 1, 1, dest);
+            fwrite(sl.h_out[b] + (size_t)slot * ZWZ_DEV_STRIDE, 1, (size_t)payload, dest);
+            if (payload == (int32_t)ZWZ_CHUNK_SIZE && sl.h_len[b][slot] >= 65510u) truncated++;
+            if (last) {
+                while (!f.md5_ready->load()) std::this_thread::yield();
+                fwrite(f.md5.data(), 1, f.md5.size(), dest);
+            }
+        }
+    };
+
+    if (nslices) start_read(0);
+    for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+        pool.wait(read_group[s & 1]);
+        rc = launch_gpu(s);
+        if (rc) break;
+        if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
+        if (s + 1 < nslices) start_read(s + 1);       // its buffers were last used by slice s-1, now complete
+        if (s >= 1) write_records(s - 1);
+    }
+    if (rc == ZWZ_OK && nslices) {
+        hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_records(nslices - 1);
+    }
+    pool.wait(read_group[0]); pool.wait(read_group[1]); pool.wait(md5_group);
+    (void)hipStreamSynchronize(c->stream);
+    free_slices(sl);
+    for (auto& f : files) close(f.fd);
+    if (ferror(dest) && rc == ZWZ_OK) rc = ZWZ_E_IO;
+    if (fclose(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
+    if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed size while it was being read"); rc = ZWZ_E_IO; }
+    if (truncated && verbose())
+        fprintf(stderr, "zwz: %u chunk payload(s) reached the reference's 65535-byte cap (lossy, like the reference)\n", truncated);
+    return rc;
+}
+
+int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int* md5_mismatches) {
+    if (!c || !src_dir || !dst_dir) return ZWZ_E_INVALID;
+    if (md5_mismatches) *md5_mismatches = 0;
+    std::vector<std::string> shards;
+    try {
+        for (const auto& e : fs::directory_iterator(src_dir))   // decompression.cpp:168-172
+            if (e.path().extension() == ".zwz") shards.push_back(e.path().string());
+    } catch (const std::exception& ex) { set_error("%s", ex.what()); return ZWZ_E_IO; }
+
+    HIPCHK(hipSetDevice(c->device));
+    Pool pool(host_threads());
+    std::atomic<int> mismatches{0};
+    std::mutex log_mutex;
+    int rc = ZWZ_OK;
+
+    for (const std::string& shard : shards) {
+        // ---- pass 1: parse records (decompression.cpp:65-92) and replay the reference's per-path
+        // sequencing (expected id + pending heap, :119-153): per output file instance, the ordered
+        // list of records that get decoded into it.
+        int fd = open(shard.c_str(), O_RDONLY);
+        if (fd < 0) { fprintf(stderr, "Error opening file: %s\n", shard.c_str()); continue; }
+        struct stat sb;
+        fstat(fd, &sb);
+        std::vector<uint8_t> blob((size_t)sb.st_size);
+        size_t got = 0;
+        while (got < blob.size()) { ssize_t k = read(fd, blob.data() + got, blob.size() - got); if (k <= 0) break; got += (size_t)k; }
+        close(fd);
+        blob.resize(got);
+
+        struct Rec { uint64_t off; uint32_t len; int32_t seq; uint8_t last; };
+        struct FileInst { std::string rel; std::vector<Rec> order; std::multimap<int32_t, Rec> pending; int32_t expected = 0; std::string md5; bool finalised = false; };
+        std::vector<FileInst> insts;
+        std::map<std::string, size_t> open_inst;
+        size_t p = 0;
+        while (p + 4 <= blob.size()) {
+            int32_t total, path_len, seq;
+            memcpy(&total, &blob[p], 4); p += 4;
+            if (p + 4 > blob.size()) break;
+            memcpy(&path_len, &blob[p], 4); p += 4;
+            if (path_len < 0 || p + (size_t)path_len + 5 > blob.size()) break;
+            std::string rel(reinterpret_cast<const char*>(&blob[p]), (size_t)path_len); p += (size_t)path_len;
+            memcpy(&seq, &blob[p], 4); p += 4;
+            const uint8_t last = blob[p++];
+            const int64_t plen = (int64_t)total - (4 + path_len + 4 + 1);
+            if (plen < 0 || plen > (int64_t)ZWZ_CHUNK_SIZE || p + (size_t)plen > blob.size()) { rc = ZWZ_E_FORMAT; break; }
+            Rec r{(uint64_t)p, (uint32_t)plen, seq, last};
+            p += (size_t)plen;
+            std::string md5;
+            if (last) { if (p + ZWZ_MD5_HEX_LEN > blob.size()) { rc = ZWZ_E_FORMAT; break; } md5.assign(reinterpret_cast<const char*>(&blob[p]), ZWZ_MD5_HEX_LEN); p += ZWZ_MD5_HEX_LEN; }
+            auto it = open_inst.find(rel);
+            if (it == open_inst.end()) { insts.push_back(FileInst{}); insts.back().rel = rel; it = open_inst.emplace(rel, insts.size() - 1).first; }
+            FileInst& fi = insts[it->second];
+            if (last) fi.md5 = md5;
+            if (fi.expected == seq) {
+                fi.order.push_back(r); fi.expected++;
+                for (auto pit = fi.pending.find(fi.expected); pit != fi.pending.end(); pit = fi.pending.find(fi.expected)) {
+                    fi.order.push_back(pit->second); fi.pending.erase(pit); fi.expected++;
+                }
+                if (last && fi.expected == seq + 1 && fi.pending.empty()) { fi.finalised = true; open_inst.erase(it); }
+            } else {
+                fi.pending.emplace(seq, r);
+            }
+        }
+        if (rc) { set_error("malformed shard %s", shard.c_str()); return rc; }
+
+        // ---- pass 2: all scheduled records, slice by slice, double-buffered; files are written and
+        // hashed by the pool, one task per file per slice (slices of a file run in order)
+        struct Job { uint32_t inst; Rec r; };
+        std::vector<Job> jobs;
+        for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
+        struct OutState { FILE* f = nullptr; Md5 md5; uint32_t remaining = 0; bool failed = false; };
+        std::vector<OutState> outs(insts.size());
+        for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
+        const uint32_t T = (uint32_t)jobs.size();
+        const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(4096u, (T + 1) / 2 + 1)));
+        Slices sl;
+        rc = make_slices(c, cap, sl);
+        if (rc) return rc;
+        const uint32_t nslices = (T + cap - 1) / cap;
+        Pool::Group fill_group[2], write_group;
+
+        auto open_out = [&](uint32_t inst) {
+            const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
+            std::error_code ec;
+            fs::path dir = fs::path(file_path).parent_path();
+            if (!dir.empty() && !fs::exists(dir, ec)) fs::create_directories(dir, ec);
+            outs[inst].f = fopen(file_path.c_str(), "wb");
+            if (!outs[inst].f) { std::lock_guard<std::mutex> l(log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); outs[inst].failed = true; }
+        };
+        auto finish_out = [&](uint32_t inst) {
+            OutState& o = outs[inst];
+            if (o.f) { fclose(o.f); o.f = nullptr; }
+            const FileInst& fi = insts[inst];
+            const std::string file_path = std::string(dst_dir) + "/" + fi.rel;
+            std::lock_guard<std::mutex> l(log_mutex);
+            if (fi.finalised) {   // decompression.cpp:132-149
+                char hex[33];
+                o.md5.hex(hex);
+                if (fi.md5 != hex) {
+                    mismatches.fetch_add(1);
+                    fprintf(stderr, "MD5 mismatch for file: %s\n", file_path.c_str());
+                    if (verbose()) printf("Expected MD5: %s\nCalculated MD5: %s\n", fi.md5.c_str(), hex);
+                } else if (verbose()) printf("MD5 match for file: %s\n", file_path.c_str());
+            } else if (!fi.pending.empty()) {
+                fprintf(stderr, "Warning: pending chunks remaining for file: %s\n", fi.rel.c_str());
+            }
+        };
+        auto start_fill = [&](uint32_t s) {
+            const int b = (int)(s & 1u);
+            const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+            for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
+                const uint32_t u1 = std::min(g1, u0 + 256);
+                pool.submit(fill_group[b], [&, b, g0, u0, u1] {
+                    for (uint32_t g = u0; g < u1; g++) {
+                        const Rec& r = jobs[g].r;
+                        memcpy(sl.h_in[b] + (size_t)(g - g0) * ZWZ_DEV_STRIDE, &blob[r.off], r.len);
+                        sl.h_off[b][g - g0] = (uint64_t)(g - g0) * ZWZ_DEV_STRIDE; sl.h_len[b][g - g0] = r.len;
+                    }
+                });
+            }
+        };
+        auto launch_gpu = [&](uint32_t s) -> int {
+            const int b = (int)(s & 1u);
+            const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
+            HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            int r = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b], sl.d_st[b]);
+            if (r) return r;
+            HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipEventRecord(sl.done[b], c->stream));
+            return ZWZ_OK;
+        };
+        auto write_slice = [&](uint32_t s) {     // one task per file that has records in this slice
+            const int b = (int)(s & 1u);
+            const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+            uint32_t g = g0;
+            while (g < g1) {
+                uint32_t e = g;
+                while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
+                const uint32_t inst = jobs[g].inst, a0 = g, a1 = e;
+                pool.submit(write_group, [&, b, g0, inst, a0, a1] {
+                    OutState& o = outs[inst];
+                    if (!o.f && !o.failed) open_out(inst);
+                    for (uint32_t k = a0; k < a1; k++) {
+                        const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
+                        const uint32_t n = sl.h_olen[b][k - g0];
+                        if (o.f) fwrite(src, 1, n, o.f);
+                        o.md5.update(src, n);
+                    }
+                    o.remaining -= a1 - a0;
+                    if (o.remaining == 0) finish_out(inst);
+                });
+                g = e;
+            }
+            pool.wait(write_group);              // the next slice of a file must follow this one
+        };
+
+        if (nslices) start_fill(0);
+        for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+            pool.wait(fill_group[s & 1]);
+            rc = launch_gpu(s);
+            if (rc) break;
+            if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
+            if (s + 1 < nslices) start_fill(s + 1);
+            if (s >= 1) write_slice(s - 1);
+        }
+        if (rc == ZWZ_OK && nslices) {
+            hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
+            if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_slice(nslices - 1);
+        }
+        pool.wait(fill_group[0]); pool.wait(fill_group[1]);
+        (void)hipStreamSynchronize(c->stream);
+        free_slices(sl);
+        // instances that never received a decodable record still get created (the reference opens on
+        // the first record of a path)
+        for (uint32_t i = 0; i < insts.size(); i++)
+            if (insts[i].order.empty()) { open_out(i); finish_out(i); }
+        if (rc) break;
+    }
+    if (md5_mismatches) *md5_mismatches = mismatches.load();
+    return rc;
+}
+
+}  // extern "C"
