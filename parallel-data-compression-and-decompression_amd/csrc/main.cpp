@@ -67,6 +67,9 @@ int main(int argc, char* argv[]) {
     zwz_ctx* ctx = nullptr;
     const int dev = device_count > 0 ? env_int(dev_vars, world_rank) % device_count : 0;
     int rc = zwz_ctx_create(dev, 0, &ctx);
+    const bool trace = getenv("ZWZ_VERBOSE") != nullptr;
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); };
+    if (trace) fprintf(stderr, "zwz: context ready at %.3f s\n", since());
     if (rc != ZWZ_OK) { fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error()); return 2; }
 
     const std::string tag = output_path + "/.zwz_" + operation;
@@ -94,7 +97,9 @@ int main(int argc, char* argv[]) {
         int bad = 0;
         rc = zwz_decompress_dir(ctx, source_path.c_str(), output_path.c_str(), &bad);
     }
+    if (trace) fprintf(stderr, "zwz: %s done at %.3f s\n", operation.c_str(), since());
     zwz_ctx_destroy(ctx);
+    if (trace) fprintf(stderr, "zwz: context destroyed at %.3f s\n", since());
     if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
     if (world_size > 1) {   // MPI_Barrier (main.cpp:144)
