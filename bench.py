@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--max-batch", type=int, default=8192)
     ap.add_argument("--cpu-sample-files", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 ranks share cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
     return ap.parse_args()
 
 
@@ -142,11 +144,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the codec has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     zwz = importlib.import_module("parallel-data-compression-and-decompression_amd")
     codec = zwz.Codec(local, args.max_batch)
@@ -178,7 +185,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
