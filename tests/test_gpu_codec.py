@@ -247,3 +247,58 @@ def test_sorted_list_written_by_cli_is_size_descending(tmp_path):
     sizes = [len(files[l]) for l in lines]
     assert sorted(lines) == sorted(files) and sizes == sorted(sizes, reverse=True)
     assert os.listdir(tmp_path / "out") == ["compressed_0.zwz"]
+
+
+def test_many_small_files_like_config4(codec, oracle, tmp_path):
+    """BASELINE config 4 shape at reduced scale: thousands of small files in nested directories
+    (one chunk per file, tiny dynamic blocks).  Shard bytes vs the oracle, then a full round trip."""
+    rs = corpus.splitmix64(4242, 4000)
+    src = tmp_path / "src"
+    names = []
+    for i in range(2000):
+        n = int(rs[2 * i] % 9000) + (0 if i % 97 else 65535)          # a few exact-multiple files too
+        kind = ("gradient", "text", "random", "lowent")[int(rs[2 * i + 1] % 4)]
+        rel = "d%02d/s%d/img_%05d.raw" % (i % 17, i % 5, i)
+        p = src / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(corpus.make(kind, 50000 + i, n % 70000))
+        names.append(rel)
+    rec = tmp_path / "list.txt"
+    rec.write_text("".join(n + "\n" for n in sorted(names, key=lambda r: -os.path.getsize(src / r))))
+    got_dir, want_dir = tmp_path / "got", tmp_path / "want"
+    got_dir.mkdir(); want_dir.mkdir()
+    for r in range(3):
+        codec.do_compression(str(src), str(got_dir), str(rec), r, 3)
+        assert oracle.compress_shard(str(src), str(want_dir), str(rec), r, 3) == 0
+    for r in range(3):
+        name = "compressed_%d.zwz" % r
+        assert sha(open(got_dir / name, "rb").read()) == sha(open(want_dir / name, "rb").read()), name
+    back, oback = tmp_path / "back", tmp_path / "oback"
+    back.mkdir(); oback.mkdir()
+    bad = codec.do_decompression(str(got_dir), str(back))
+    obad = sum(oracle.decompress_shard(str(want_dir / ("compressed_%d.zwz" % r)), str(oback)) for r in range(3))
+    assert bad == obad > 0                                              # files with a truncated chunk come back short
+    for rel in names:
+        assert open(back / rel, "rb").read() == open(oback / rel, "rb").read(), rel
+
+
+def test_one_large_file_like_config5(codec, oracle, tmp_path):
+    """BASELINE config 5 shape at reduced scale: one large file = one shard of ~1000 records decoded
+    chunk-parallel (the reference decodes such a shard serially on one thread)."""
+    src = tmp_path / "src"
+    src.mkdir()
+    big = b"".join(corpus.text_like(600 + i, 1 << 20) for i in range(48)) + corpus.random_bytes(9, 3 * 65535)
+    (src / "big.bin").write_bytes(big)
+    rec = tmp_path / "list.txt"
+    rec.write_text("big.bin\n")
+    got_dir, want_dir = tmp_path / "got", tmp_path / "want"
+    got_dir.mkdir(); want_dir.mkdir()
+    codec.do_compression(str(src), str(got_dir), str(rec), 0, 1)
+    assert oracle.compress_shard(str(src), str(want_dir), str(rec), 0, 1) == 0
+    assert open(got_dir / "compressed_0.zwz", "rb").read() == open(want_dir / "compressed_0.zwz", "rb").read()
+    back, oback = tmp_path / "back", tmp_path / "oback"
+    back.mkdir(); oback.mkdir()
+    bad = codec.do_decompression(str(got_dir), str(back))
+    obad = oracle.decompress_shard(str(want_dir / "compressed_0.zwz"), str(oback))
+    assert bad == obad == 1                                             # the random tail is truncated -> MD5 mismatch
+    assert open(back / "big.bin", "rb").read() == open(oback / "big.bin", "rb").read()
