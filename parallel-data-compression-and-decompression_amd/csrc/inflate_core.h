@@ -70,6 +70,14 @@ struct BitReader {
         v = peek(k); drop(k);
         return true;
     }
+    // absolute bit position of the next unread bit / reposition at an absolute bit
+    ZWZ_HD uint32_t bit_pos() const { return pos * 8u - bits; }
+    ZWZ_HD void seek_bit(uint32_t bp) {
+        pos = bp >> 3; hold = 0; bits = 0;
+        refill();
+        const uint32_t sk = bp & 7u;
+        if (sk && bits >= sk) drop(sk);
+    }
 };
 
 // Build fast + canonical tables from code lengths.  Returns 0 ok, -1 over-subscribed,
@@ -221,11 +229,11 @@ ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t
 // Returns the symbol count; *block_done is set at end-of-block or when decoding stops.
 // out_cap bounds the output slot (65535): a symbol that would cross it stops with kInfOverflow.
 ZWZ_HD uint32_t inflate_decode_batch(InflateState& st, const InflateTables& t, uint32_t out_cap, uint32_t* batch,
-                                     uint32_t* pos, bool& block_done) {
+                                     uint32_t* pos, bool& block_done, uint32_t max_syms = kBatch) {
     BitReader& br = st.br;
     uint32_t k = 0;
     block_done = false;
-    while (k < kBatch) {
+    while (k < max_syms) {
         int sym = decode_symbol(br, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym);
         if (sym < 0) { st.status = sym == -1 ? kInfNeedInput : kInfDataError; block_done = true; break; }
         if (sym < 256) {

@@ -946,20 +946,95 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             }
             if (__builtin_amdgcn_readfirstlane(stop)) break;
         } else {
-            uint32_t done = 0;
-            while (!done) {
-                uint32_t k = 0;
-                top_up(st.br.pos);
-                if (lane == 0) { bool d; k = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d); done = d; }
-                k = __builtin_amdgcn_readfirstlane(k); done = __builtin_amdgcn_readfirstlane(done);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // lane 0's LDS batch -> all lanes
-                const uint32_t sv = lane < k ? m.batch[lane] : 0u, sp = lane < k ? m.pos[lane] : 0u;
+            // Huffman block.  Decoding is sequential only in where symbols START; what a symbol is,
+            // given its start bit, is a pure table lookup.  So every lane decodes the symbol that would
+            // start at each of its four bit offsets of a 256-bit window (window bit o <-> lane o & 63,
+            // slot o >> 6), and a short scalar loop then hops through the true chain with v_readlane,
+            // dropping the symbols into the batch registers with v_writelane.  (Lane 0 decoding alone
+            // cost ~1900 cycles per symbol.)  Codes longer than the fast tables, and anything odd, fall
+            // back to the sequential decoder for one symbol, which also keeps zlib's exact error and
+            // truncation behaviour.
+            enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
+            uint32_t bp = 0, opos_u = 0;
+            if (lane == 0) { bp = st.br.bit_pos(); opos_u = st.out_pos; }
+            bp = __builtin_amdgcn_readfirstlane(bp); opos_u = __builtin_amdgcn_readfirstlane(opos_u);
+            const uint32_t total_bits = nin * 8u;
+            uint32_t block_done = 0, stop_status = kInfRunning;
+            while (!block_done) {
+                top_up(bp >> 3);
+                uint32_t inf[4], val[4];
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) {
+                    const uint32_t a = bp + r * 64u + lane;
+                    const int32_t avail = (int32_t)total_bits - (int32_t)a;
+                    const uint32_t byte = (a >> 3) & (kInfRing - 1u);
+                    const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
+                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);      // >= 57 valid bits
+                    uint32_t kind = kSlow, nb = 0, v = 0;
+                    const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
+                    const uint32_t l = e & 15u, s = e >> 4;
+                    if (e != 0) {
+                        if (s < 256u) { kind = kLit; nb = l; v = s; }
+                        else if (s == 256u) { kind = kEob; nb = l; }
+                        else {
+                            const uint32_t c = s - 257u;
+                            kind = kErr;
+                            if (c < 29u) {
+                                const uint32_t xb = length_extra_bits(c);
+                                const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
+                                const uint64_t rest = bits >> (l + xb);
+                                const uint32_t de = m.t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+                                const uint32_t dl = de & 15u, d = de >> 4;
+                                kind = kSlow;
+                                if (de != 0) {
+                                    kind = kErr;
+                                    if (d < 30u) {
+                                        const uint32_t dxb = dist_extra_bits(d);
+                                        const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
+                                        kind = kMatch; nb = l + xb + dl + dxb; v = (len << 16) | dist;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
+                    inf[r] = kind | (nb << 3); val[r] = v;
+                }
+                // hop through the real symbol chain (wave-uniform)
+                uint32_t cur = 0, kcnt = 0, sv = 0, sp = 0, stop = 0xffu;
+                while (cur < 256u && kcnt < kBatch) {
+                    const uint32_t ln = cur & 63u;
+                    uint32_t info, v;
+                    switch (cur >> 6) {
+                        case 0: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[0], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[0], ln); break;
+                        case 1: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[1], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[1], ln); break;
+                        case 2: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[2], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[2], ln); break;
+                        default: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[3], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[3], ln); break;
+                    }
+                    const uint32_t kind = info & 7u, nb = info >> 3;
+                    if (kind == kLit) {
+                        if (opos_u >= kChunk) { stop = kErr; stop_status = kInfOverflow; break; }
+                        if (lane == kcnt) { sv = v; sp = opos_u; }
+                        opos_u += 1u; kcnt++; cur += nb;
+                    } else if (kind == kMatch) {
+                        const uint32_t len = v >> 16, dist = v & 0xffffu;
+                        if (dist > opos_u) { stop = kErr; stop_status = kInfDataError; break; }          // too far back
+                        if (opos_u + len > kChunk) { stop = kErr; stop_status = kInfOverflow; break; }
+                        if (lane == kcnt) { sv = v; sp = opos_u; }
+                        opos_u += len; kcnt++; cur += nb;
+                    } else if (kind == kEob) { cur += nb; stop = kEob; break; }
+                    else { stop = kind; if (kind == kNeed) stop_status = kInfNeedInput; else if (kind == kErr) stop_status = kInfDataError; break; }
+                }
+                bp += cur;
+                // the wave moves the bytes of this batch
+                const uint32_t k = kcnt;
                 if (lane < k && sv < 256u) dst[sp] = (uint8_t)sv;
                 uint64_t matches = __ballot(lane < k && sv >= 256u);
                 while (matches) {   // in order: a match may read what an earlier symbol of this batch wrote
                     const uint32_t l = (uint32_t)__builtin_ctzll(matches);
                     matches &= matches - 1;
-                    const uint32_t mv = __builtin_amdgcn_readlane(sv, l), mp = __builtin_amdgcn_readlane(sp, l);
+                    const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)sv, l), mp = (uint32_t)__builtin_amdgcn_readlane((int)sp, l);
                     const uint32_t len = mv >> 16, dist = mv & 0xffffu;
                     const uint32_t from = mp - dist, span = len < dist ? len : dist;
                     if (from + span > fenced) {
@@ -969,10 +1044,46 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     }
                     for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = dst[from + (i % dist)];
                 }
+                if (stop == kEob) block_done = 1;
+                else if (stop == kSlow) {
+                    // one symbol through the sequential decoder (long code, or its exact failure mode)
+                    uint32_t k1 = 0, d1 = 0, nbp = bp, nop = opos_u, stt = kInfRunning;
+                    if (lane == 0) {
+                        st.br.seek_bit(bp); st.out_pos = opos_u;
+                        bool d;
+                        k1 = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d, 1u);
+                        d1 = d; nbp = st.br.bit_pos(); nop = st.out_pos; stt = st.status;
+                    }
+                    k1 = __builtin_amdgcn_readfirstlane(k1); d1 = __builtin_amdgcn_readfirstlane(d1);
+                    bp = __builtin_amdgcn_readfirstlane(nbp); opos_u = __builtin_amdgcn_readfirstlane(nop);
+                    stt = __builtin_amdgcn_readfirstlane(stt);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (k1) {
+                        const uint32_t mv = m.batch[0], mp = m.pos[0];
+                        if (mv < 256u) { if (lane == 0) dst[mp] = (uint8_t)mv; }
+                        else {
+                            const uint32_t len = mv >> 16, dist = mv & 0xffffu;
+                            const uint32_t from = mp - dist, span = len < dist ? len : dist;
+                            if (from + span > fenced) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                                __builtin_amdgcn_s_waitcnt(0);
+                                fenced = mp;
+                            }
+                            for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = dst[from + (i % dist)];
+                        }
+                    }
+                    if (d1) { block_done = 1; stop_status = stt; }
+                } else if (stop != 0xffu) { block_done = 1; }          // need / error / overflow: status already set
             }
-            uint32_t stop = 0;
-            if (lane == 0) stop = st.status != kInfRunning;
-            if (__builtin_amdgcn_readfirstlane(stop)) break;
+            // hand the position back to lane 0's reader for the next block header
+            uint32_t halt = 0;
+            if (lane == 0) {
+                st.out_pos = opos_u;
+                if (stop_status != kInfRunning) st.status = stop_status;
+                else st.br.seek_bit(bp);
+                halt = st.status != kInfRunning;
+            }
+            if (__builtin_amdgcn_readfirstlane(halt)) break;
         }
         uint32_t fin = 0;
         if (lane == 0 && st.last) { st.status = kInfEnd; fin = 1; }
