@@ -1027,22 +1027,48 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     else { stop = kind; if (kind == kNeed) stop_status = kInfNeedInput; else if (kind == kErr) stop_status = kInfDataError; break; }
                 }
                 bp += cur;
-                // the wave moves the bytes of this batch
+                // The wave moves the bytes of this batch, one output byte per lane per trip: find the
+                // symbol that produces the byte (binary search over the batch's start offsets), follow
+                // back-references that point into this same batch until they land on a literal of the
+                // batch or on output of an earlier batch, then load/store.  All loads of a trip are in
+                // flight together (copying match by match cost one L2 round trip per match: ~9 ms a chunk).
                 const uint32_t k = kcnt;
-                if (lane < k && sv < 256u) dst[sp] = (uint8_t)sv;
-                uint64_t matches = __ballot(lane < k && sv >= 256u);
-                while (matches) {   // in order: a match may read what an earlier symbol of this batch wrote
-                    const uint32_t l = (uint32_t)__builtin_ctzll(matches);
-                    matches &= matches - 1;
-                    const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)sv, l), mp = (uint32_t)__builtin_amdgcn_readlane((int)sp, l);
-                    const uint32_t len = mv >> 16, dist = mv & 0xffffu;
-                    const uint32_t from = mp - dist, span = len < dist ? len : dist;
-                    if (from + span > fenced) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        __builtin_amdgcn_s_waitcnt(0);
-                        fenced = mp;
+                const uint32_t bstart = __builtin_amdgcn_readfirstlane(k ? (uint32_t)__builtin_amdgcn_readlane((int)sp, 0) : opos_u);
+                const uint32_t bbytes = opos_u - bstart;
+                // the batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
+                // owners here; indexed LDS reads are also cheaper than eight bpermutes)
+                m.batch[lane] = sv; m.pos[lane] = lane < k ? sp : 0xffffffffu;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t stp = 32; stp >= 1; stp >>= 1) { const uint32_t q = m.pos[(lo + stp) & 63u]; if (q <= pos) lo += stp; }
+                    ov = m.batch[lo]; op = m.pos[lo];
+                };
+                bool need_fence = false;
+                for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
+                    const uint32_t pos = bstart + j0 + lane;
+                    const bool in = j0 + lane < bbytes;
+                    uint32_t ov = 0, op = 0;
+                    owner(in ? pos : bstart, ov, op);
+                    uint32_t src = 0; bool lit = ov < 256u;
+                    if (!lit) { const uint32_t d = ov & 0xffffu; src = op - d + ((pos - op) % d); }
+                    // chase references into this batch (wave-uniform loop, lanes drop out as they resolve)
+                    while (__ballot(in && !lit && src >= bstart)) {
+                        const bool go2 = in && !lit && src >= bstart;
+                        uint32_t ov2 = 0, op2 = 0;
+                        owner(go2 ? src : bstart, ov2, op2);
+                        if (go2) {
+                            if (ov2 < 256u) { lit = true; ov = ov2; }
+                            else { const uint32_t d = ov2 & 0xffffu; src = op2 - d + ((src - op2) % d); }
+                        }
                     }
-                    for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = dst[from + (i % dist)];
+                    const uint64_t far = __ballot(in && !lit && src + 1u > fenced);
+                    if (far) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = bstart; }
+                    // back-references read bytes this CU stored a moment ago: agent-scope (sc1) loads are served
+                    // by L2 and cannot hit a stale L1 line that was cached before the store
+                    if (in) dst[pos] = lit ? (uint8_t)ov : __hip_atomic_load(&dst[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)need_fence;
                 }
                 if (stop == kEob) block_done = 1;
                 else if (stop == kSlow) {
@@ -1069,7 +1095,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                                 __builtin_amdgcn_s_waitcnt(0);
                                 fenced = mp;
                             }
-                            for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = dst[from + (i % dist)];
+                            for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = __hip_atomic_load(&dst[from + (i % dist)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                     if (d1) { block_done = 1; stop_status = stt; }

@@ -243,3 +243,56 @@ extern "C" int emu_parse_blocks_check(const uint8_t* in, uint32_t L) {
     if (n_sym != ref.n_sym || last_is_match != ref.last_is_match) return 1;
     return 0;
 }
+
+// Batch copy the way the inflate kernel does it: one output byte per lane, owner by binary search
+// over the batch's start offsets, references into the same batch chased down to a literal or to
+// output of an earlier batch.
+extern "C" uint32_t emu_inflate_bytewise(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap, uint32_t* status, uint32_t batch_syms) {
+    InflateState st;
+    static InflateTables t;
+    uint8_t lens[320];
+    uint32_t batch[kBatch], pos[kBatch];
+    if (inflate_begin(st, in, n)) {
+        for (;;) {
+            uint32_t src = 0, len = 0;
+            uint32_t kind = inflate_block_header(st, t, lens, src, len);
+            if (kind == kBlkStop) break;
+            if (kind == kBlkStored) {
+                if (st.out_pos + len > cap) { st.status = kInfOverflow; break; }
+                memcpy(out + st.out_pos, in + src, len);
+                st.out_pos += len;
+                if (st.status != kInfRunning) break;
+            } else {
+                bool done = false;
+                while (!done) {
+                    uint32_t k = inflate_decode_batch(st, t, cap, batch, pos, done, batch_syms);
+                    if (!k) continue;
+                    const uint32_t bstart = pos[0], bend = st.out_pos;
+                    uint32_t sp[64], sv[64];
+                    for (uint32_t i = 0; i < 64; i++) { sp[i] = i < k ? pos[i] : 0xffffffffu; sv[i] = i < k ? batch[i] : 0; }
+                    auto owner = [&](uint32_t p, uint32_t& ov, uint32_t& op) {
+                        uint32_t lo = 0;
+                        for (uint32_t stp = 32; stp >= 1; stp >>= 1) if (sp[(lo + stp) & 63] <= p) lo += stp;
+                        ov = sv[lo]; op = sp[lo];
+                    };
+                    std::vector<uint8_t> res(bend - bstart);
+                    for (uint32_t p = bstart; p < bend; p++) {
+                        uint32_t ov, op; owner(p, ov, op);
+                        bool lit = ov < 256; uint32_t s = 0;
+                        if (!lit) { uint32_t d = ov & 0xffff; s = op - d + ((p - op) % d); }
+                        while (!lit && s >= bstart) {
+                            uint32_t ov2, op2; owner(s, ov2, op2);
+                            if (ov2 < 256) { lit = true; ov = ov2; } else { uint32_t d = ov2 & 0xffff; s = op2 - d + ((s - op2) % d); }
+                        }
+                        res[p - bstart] = lit ? (uint8_t)ov : out[s];
+                    }
+                    memcpy(out + bstart, res.data(), res.size());
+                }
+                if (st.status != kInfRunning) break;
+            }
+            if (st.last) { st.status = kInfEnd; break; }
+        }
+    }
+    *status = st.status;
+    return st.out_pos;
+}
