@@ -884,6 +884,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 // (16 bytes per lane, coalesced): a decode call consumes < 1 KiB, so topping the ring up to
 // pos + 1 KiB before every call keeps lane 0 off global memory entirely.
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
+constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
 
 struct InflateWaveMem {
     InflateTables t;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
         } else {
             // Huffman block.  Decoding is sequential only in where symbols START; what a symbol is,
             // given its start bit, is a pure table lookup.  So every lane decodes the symbol that would
-            // start at each of its four bit offsets of a 256-bit window (window bit o <-> lane o & 63,
+            // start at each of its kWinSlots bit offsets of a 256-bit window (window bit o <-> lane o & 63,
             // slot o >> 6), and a short scalar loop then hops through the true chain with v_readlane,
             // dropping the symbols into the batch registers with v_writelane.  (Lane 0 decoding alone
             // cost ~1900 cycles per symbol.)  Codes longer than the fast tables, and anything odd, fall
@@ -962,9 +963,9 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             uint32_t block_done = 0, stop_status = kInfRunning;
             while (!block_done) {
                 top_up(bp >> 3);
-                uint32_t inf[4], val[4];
+                uint32_t inf[kWinSlots], val[kWinSlots];
 #pragma unroll
-                for (uint32_t r = 0; r < 4; r++) {
+                for (uint32_t r = 0; r < kWinSlots; r++) {
                     const uint32_t a = bp + r * 64u + lane;
                     const int32_t avail = (int32_t)total_bits - (int32_t)a;
                     const uint32_t byte = (a >> 3) & (kInfRing - 1u);
@@ -1003,15 +1004,12 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 }
                 // hop through the real symbol chain (wave-uniform)
                 uint32_t cur = 0, kcnt = 0, sv = 0, sp = 0, stop = 0xffu;
-                while (cur < 256u && kcnt < kBatch) {
+                while (cur < 64u * kWinSlots && kcnt < kBatch) {
                     const uint32_t ln = cur & 63u;
-                    uint32_t info, v;
-                    switch (cur >> 6) {
-                        case 0: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[0], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[0], ln); break;
-                        case 1: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[1], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[1], ln); break;
-                        case 2: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[2], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[2], ln); break;
-                        default: info = (uint32_t)__builtin_amdgcn_readlane((int)inf[3], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[3], ln); break;
-                    }
+                    uint32_t info = 0, v = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++)      // wave-uniform select of the slot
+                        if ((cur >> 6) == r) { info = (uint32_t)__builtin_amdgcn_readlane((int)inf[r], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[r], ln); }
                     const uint32_t kind = info & 7u, nb = info >> 3;
                     if (kind == kLit) {
                         if (opos_u >= kChunk) { stop = kErr; stop_status = kInfOverflow; break; }

@@ -296,3 +296,39 @@ extern "C" uint32_t emu_inflate_bytewise(const uint8_t* in, uint32_t n, uint8_t*
     *status = st.status;
     return st.out_pos;
 }
+
+// statistics for tuning the inflate fast tables: how many symbols miss the lit/len or distance table
+extern "C" void emu_fast_table_stats(const uint8_t* in, uint32_t n, uint32_t lit_bits, uint32_t dist_bits, uint64_t* out4) {
+    InflateState st; static InflateTables t; uint8_t lens[320];
+    uint64_t nsym = 0, lit_miss = 0, nmatch = 0, dist_miss = 0;
+    if (!inflate_begin(st, in, n)) return;
+    for (;;) {
+        uint32_t src = 0, len = 0;
+        uint32_t kind = inflate_block_header(st, t, lens, src, len);
+        if (kind != kBlkHuffman) break;
+        // code lengths of the block are in lens[] only for dynamic blocks; recompute from tables: walk symbols
+        BitReader& br = st.br;
+        for (;;) {
+            if (br.bits < 15) br.refill();
+            // lit/len code length: decode canonically
+            BitReader save = br;
+            int sym = decode_symbol(br, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym);
+            if (sym < 0) goto done;
+            uint32_t used = br.bit_pos() - save.bit_pos();
+            nsym++; if (used > lit_bits) lit_miss++;
+            if (sym < 256) continue;
+            if (sym == 256) break;
+            uint32_t c = sym - 257, xv;
+            br.take(length_extra_bits(c), xv);
+            BitReader s2 = br;
+            int ds = decode_symbol(br, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym);
+            if (ds < 0) goto done;
+            uint32_t du = br.bit_pos() - s2.bit_pos();
+            nmatch++; if (du > dist_bits) dist_miss++;
+            br.take(dist_extra_bits(ds), xv);
+        }
+        if (st.last) break;
+    }
+done:
+    out4[0] = nsym; out4[1] = lit_miss; out4[2] = nmatch; out4[3] = dist_miss;
+}
