@@ -565,19 +565,71 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 // sorts the histogram, lane 0 merges it into the optimal Huffman cost, and if that lower bound
 // already forces "stored" the block is done.  Otherwise lane 0 runs zlib's exact tree construction
 // with its scratch in LDS.
-static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint32_t n, uint16_t* sorted, uint32_t* m_out) {
+// Sorting: composite keys (count << 9 | symbol) make the order total, so a lane's rank is a plain
+// count of smaller keys; the keys are read back four per LDS access and compared against all of the
+// lane's (up to five) own keys at once.  (The first version re-read one count per compare and spent
+// 250 k cycles per block waiting on LDS.)
+constexpr uint32_t kSortKeys = 288;   // kLCodes rounded up to a multiple of 4
+static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint32_t n, uint32_t* keys, uint16_t* sorted, uint32_t* m_out) {
     // ascending order of the non-zero counts; ties by symbol (any order works for the cost)
     const uint32_t lane = lane_id();
-    uint32_t used = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const uint32_t fi = i < n ? freq[i] : 0u;
-        uint32_t rank = 0;
-        if (fi) for (uint32_t j = 0; j < n; j++) { const uint32_t fj = freq[j]; rank += (fj != 0u) & ((fj < fi) | ((fj == fi) & (j < i))); }
-        if (fi) sorted[rank] = (uint16_t)fi;
-        used += (uint32_t)__popcll(__ballot(fi != 0));
+    const uint32_t n4 = (n + 3u) & ~3u;
+    uint32_t k[5], rank[5] = {0, 0, 0, 0, 0}, zeros = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 5; r++) {
+        const uint32_t i = lane + 64u * r;
+        k[r] = i < n ? ((uint32_t)freq[i] << 9) | i : 0xffffffffu;
+        if (i < n4) keys[i] = k[r];
+        zeros += (uint32_t)__popcll(__ballot(i < n && freq[i] == 0));
     }
-    *m_out = used;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+    const uint32_t rounds = (n + 63u) / 64u;            // wave-uniform: own keys in use
+#pragma unroll 2
+    for (uint32_t j = 0; j < n4 / 4u; j++) {
+        const uint4 q = k4[j];
+#pragma unroll
+        for (uint32_t r = 0; r < 5; r++)
+            if (r < rounds) rank[r] += (uint32_t)(q.x < k[r]) + (uint32_t)(q.y < k[r]) + (uint32_t)(q.z < k[r]) + (uint32_t)(q.w < k[r]);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 5; r++) {
+        const uint32_t i = lane + 64u * r;
+        if (i < n && (k[r] >> 9) != 0) sorted[rank[r] - zeros] = (uint16_t)(k[r] >> 9);
+    }
+    *m_out = n - zeros;
+}
+
+// Optimal prefix-code cost of ascending weights (huffman_cost_sorted's two-queue merge), run by the
+// whole wave: a 64-entry window of each queue sits in one VGPR, the merge's four candidates come
+// out of it with v_readlane at scalar speed, and new internal nodes are dropped into the window's
+// lane (and into LDS, for when the window moves on).  No step waits on LDS.
+static __device__ __forceinline__ uint32_t huffman_cost_wave(const uint16_t* sorted, uint32_t m, uint32_t* queue) {
+    if (m < 2) return 0;
+    constexpr uint32_t kInf = 0x7fffffffu;
+    const uint32_t lane = lane_id();
+    uint32_t li = 0, qi = 0, qn = 0, cost = 0, lbase = 0, qbase = 0;
+    uint32_t lw = lane < m ? (uint32_t)sorted[lane] : kInf, qw = kInf;
+    for (uint32_t step = 1; step < m; step++) {
+        if (li - lbase > 61u) { lbase = li; lw = lbase + lane < m ? (uint32_t)sorted[lbase + lane] : kInf; }
+        if (qi - qbase > 61u) { qbase = qi; qw = qbase + lane < qn ? queue[qbase + lane] : kInf; }
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)(li - lbase));
+        const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)(li - lbase + 1u));
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)qw, (int)(qi - qbase));
+        const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)qw, (int)(qi - qbase + 1u));
+        uint32_t sum;
+        if (l0 <= q0) {
+            if (l1 <= q0) { sum = l0 + l1; li += 2; } else { sum = l0 + q0; li++; qi++; }
+        } else {
+            if (l0 <= q1) { sum = q0 + l0; li++; qi++; } else { sum = q0 + q1; qi += 2; }
+        }
+        cost += sum;
+        if (lane == 0) queue[qn] = sum;
+        if (lane == qn - qbase) qw = sum;               // qn - qbase >= 64: no lane, the refill picks it up from LDS
+        qn++;
+    }
+    return cost;
 }
 
 __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
@@ -587,6 +639,7 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     __shared__ uint32_t hdr[kHdrWords];
     __shared__ uint16_t lf[kLCodes], df[kDCodes];
     __shared__ uint16_t sorted[kLCodes + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[kSortKeys];
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
     if (b >= info[chunk].n_blocks) return;
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
@@ -615,17 +668,14 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
         for (uint32_t d = 32; d >= 1; d >>= 1) {
             pr.static_len += __shfl_xor(pr.static_len, d); pr.extra_bits += __shfl_xor(pr.extra_bits, d); pr.used += __shfl_xor(pr.used, d);
         }
-        wave_rank_sort(lf, kLCodes, sorted, &m_l);
+        wave_rank_sort(lf, kLCodes, keys, sorted, &m_l);
         __syncthreads();
-        uint32_t hl = 0, hd = 0;
-        if (threadIdx.x == 0) hl = huffman_cost_sorted(sorted, m_l, queue);
+        const uint32_t hl = huffman_cost_wave(sorted, m_l, queue);
         __syncthreads();
-        wave_rank_sort(df, kDCodes, sorted, &m_d);
+        wave_rank_sort(df, kDCodes, keys, sorted, &m_d);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            hd = huffman_cost_sorted(sorted, m_d, queue);
-            certain = stored_is_certain(pr, hl, hd, stored_len, stored_ok) ? 1u : 0u;
-        }
+        const uint32_t hd = huffman_cost_wave(sorted, m_d, queue);
+        certain = stored_is_certain(pr, hl, hd, stored_len, stored_ok) ? 1u : 0u;
         certain = __builtin_amdgcn_readfirstlane(certain);
     }
     if (certain) {
