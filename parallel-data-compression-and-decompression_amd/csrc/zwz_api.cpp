@@ -247,6 +247,8 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
     a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));
+    static_assert(kMaxBlocks * sizeof(BlockProbe) <= kLinkStride * sizeof(uint16_t), "probes alias the link array");
+    a.probes = reinterpret_cast<BlockProbe*>(a.links);
 }
 
 int ensure_staging(zwz_ctx* c, uint32_t m) {

@@ -44,6 +44,17 @@ struct BlockOut {
     uint8_t dlen[kDCodes + 2];
 };
 
+// Stored-block shortcut, stage 1 -> stage 2: a block's histograms sorted ascending, plus the exact
+// sums the lower bound needs (huff_core.h: stored_is_certain).
+struct BlockProbe {
+    uint32_t static_len, extra_bits, used, m_l, m_d, stored_len;
+    uint32_t state;               // 0: no shortcut (build the trees), 1: probe filled in, 2: "stored" is certain
+    uint32_t pad;
+    uint16_t lit[288];            // ascending non-zero literal/length counts, m_l of them
+    uint16_t dist[32];            // ascending non-zero distance counts, m_d of them
+};
+static_assert(sizeof(BlockProbe) == 32 + 640, "BlockProbe layout");
+
 struct DeflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned
     uint8_t* out; uint64_t out_stride; uint32_t* out_len;                            // out_stride % 4 == 0, >= 65536
@@ -51,6 +62,7 @@ struct DeflateArgs {
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst; uint64_t* m32;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
+    BlockProbe* probes;        // kMaxBlocks per chunk; aliases `links`, which is dead once lz_match has run
 };
 
 struct InflateArgs {

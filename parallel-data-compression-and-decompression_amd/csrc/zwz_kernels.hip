@@ -561,17 +561,22 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
-// plan: one wave per (chunk, block).  First the stored-block shortcut (huff_core.h): the wave rank-
-// sorts the histogram, lane 0 merges it into the optimal Huffman cost, and if that lower bound
-// already forces "stored" the block is done.  Otherwise lane 0 runs zlib's exact tree construction
-// with its scratch in LDS.
+// plan, in three launches.
+//   plan_probe (one wave per block): the stored-block shortcut's parallel half -- exact static_len /
+//       extra bits / used codes, and both histograms rank-sorted ascending -> BlockProbe.
+//   plan_cost  (one LANE per block): the optimal Huffman cost of the sorted counts by two-queue
+//       merge, 64 blocks per wave, then huff_core.h's stored_is_certain.  The merge is a chain of
+//       ~m dependent steps; a wave per block spends them on one lane (and on the CU's one scalar
+//       issue slot per cycle when written with readlanes -- measured 560 cycles per step with 20
+//       such waves on a CU), a lane per block runs 64 chains in each instruction.
+//   plan       (one wave per block): blocks the shortcut did not settle get zlib's exact tree
+//       construction on lane 0 with its scratch in LDS.
 // Sorting: composite keys (count << 9 | symbol) make the order total, so a lane's rank is a plain
 // count of smaller keys; the keys are read back four per LDS access and compared against all of the
-// lane's (up to five) own keys at once.  (The first version re-read one count per compare and spent
-// 250 k cycles per block waiting on LDS.)
+// lane's (up to five) own keys at once.
 constexpr uint32_t kSortKeys = 288;   // kLCodes rounded up to a multiple of 4
-static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint32_t n, uint32_t* keys, uint16_t* sorted, uint32_t* m_out) {
-    // ascending order of the non-zero counts; ties by symbol (any order works for the cost)
+static __device__ __forceinline__ uint32_t wave_rank_sort(const uint16_t* freq, uint32_t n, uint32_t* keys, uint16_t* sorted) {
+    // ascending order of the non-zero counts (ties by symbol; any order gives the same cost) -> sorted[0..m), returns m
     const uint32_t lane = lane_id();
     const uint32_t n4 = (n + 3u) & ~3u;
     uint32_t k[5], rank[5] = {0, 0, 0, 0, 0}, zeros = 0;
@@ -580,7 +585,7 @@ static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint
         const uint32_t i = lane + 64u * r;
         k[r] = i < n ? ((uint32_t)freq[i] << 9) | i : 0xffffffffu;
         if (i < n4) keys[i] = k[r];
-        zeros += (uint32_t)__popcll(__ballot(i < n && freq[i] == 0));
+        zeros += (uint32_t)__popcll(__ballot(i < n && (k[r] >> 9) == 0));
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -598,90 +603,121 @@ static __device__ __forceinline__ void wave_rank_sort(const uint16_t* freq, uint
         const uint32_t i = lane + 64u * r;
         if (i < n && (k[r] >> 9) != 0) sorted[rank[r] - zeros] = (uint16_t)(k[r] >> 9);
     }
-    *m_out = n - zeros;
+    return n - zeros;
 }
 
-// Optimal prefix-code cost of ascending weights (huffman_cost_sorted's two-queue merge), run by the
-// whole wave: a 64-entry window of each queue sits in one VGPR, the merge's four candidates come
-// out of it with v_readlane at scalar speed, and new internal nodes are dropped into the window's
-// lane (and into LDS, for when the window moves on).  No step waits on LDS.
-static __device__ __forceinline__ uint32_t huffman_cost_wave(const uint16_t* sorted, uint32_t m, uint32_t* queue) {
-    if (m < 2) return 0;
+__global__ __launch_bounds__(64) void plan_probe_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
+                                                        BlockProbe* __restrict__ probes) {
+    __shared__ uint16_t lf[kLCodes + 2], df[kDCodes + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[kSortKeys];
+    const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
+    BlockProbe* pb = probes + blockIdx.x;
+    const BlockInfo* bi = blocks + blockIdx.x;
+    uint32_t stored_len = 0;
+    bool probe = b < info[chunk].n_blocks;
+    if (probe) {
+        stored_len = bi->end - bi->start;
+        probe = stored_len > 0 && !(bi->flush_pos >= kSlidePos && bi->start < kWSize);   // "stored" must be allowed at all
+    }
+    if (!probe) { if (threadIdx.x == 0) pb->state = 0; return; }
+    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
+    if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
+    __syncthreads();
+    // exact static_len / extra bits / used codes: five symbols per lane, wave reduction
+    StoredProbe pr{0, 0, 0};
+    for (uint32_t n = threadIdx.x; n < kLCodes + kDCodes; n += 64) {
+        const bool lit = n < kLCodes;
+        const uint32_t f = lit ? lf[n] : df[n - kLCodes];
+        if (!f) continue;
+        const uint32_t x = lit ? (n >= 257u ? length_extra_bits(n - 257u) : 0u) : dist_extra_bits(n - kLCodes);
+        pr.static_len += f * ((lit ? static_lit_len(n) : 5u) + x); pr.extra_bits += f * x; pr.used++;
+    }
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        pr.static_len += __shfl_xor(pr.static_len, d); pr.extra_bits += __shfl_xor(pr.extra_bits, d); pr.used += __shfl_xor(pr.used, d);
+    }
+    const uint32_t m_l = wave_rank_sort(lf, kLCodes, keys, pb->lit);
+    __syncthreads();
+    const uint32_t m_d = wave_rank_sort(df, kDCodes, keys, pb->dist);
+    if (threadIdx.x == 0) {
+        pb->static_len = pr.static_len; pb->extra_bits = pr.extra_bits; pb->used = pr.used;
+        pb->m_l = m_l; pb->m_d = m_d; pb->stored_len = stored_len; pb->state = 1;
+    }
+}
+
+// Two-queue merge on one lane, in place: a[0..m) ascending leaves.  Internal node k is written to
+// a[k]; that slot is always a leaf already consumed (after k merges 2k items are gone, of which at
+// most k were internal nodes, so at least k leaves -- and a step reads its inputs before it writes).
+// All lanes run the loop to `steps` = the wave's largest m; a lane is live while step < its own m.
+static __device__ __forceinline__ uint32_t lane_huffman_cost(uint16_t* a, uint32_t m, uint32_t steps) {
     constexpr uint32_t kInf = 0x7fffffffu;
-    const uint32_t lane = lane_id();
-    uint32_t li = 0, qi = 0, qn = 0, cost = 0, lbase = 0, qbase = 0;
-    uint32_t lw = lane < m ? (uint32_t)sorted[lane] : kInf, qw = kInf;
-    for (uint32_t step = 1; step < m; step++) {
-        if (li - lbase > 61u) { lbase = li; lw = lbase + lane < m ? (uint32_t)sorted[lbase + lane] : kInf; }
-        if (qi - qbase > 61u) { qbase = qi; qw = qbase + lane < qn ? queue[qbase + lane] : kInf; }
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)(li - lbase));
-        const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)lw, (int)(li - lbase + 1u));
-        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)qw, (int)(qi - qbase));
-        const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)qw, (int)(qi - qbase + 1u));
-        uint32_t sum;
-        if (l0 <= q0) {
-            if (l1 <= q0) { sum = l0 + l1; li += 2; } else { sum = l0 + q0; li++; qi++; }
-        } else {
-            if (l0 <= q1) { sum = q0 + l0; li++; qi++; } else { sum = q0 + q1; qi += 2; }
+    uint32_t li = 0, qi = 0, qn = 0, cost = 0;
+    for (uint32_t step = 1; step < steps; step++) {
+        if (step < m) {
+            const uint32_t l0 = li < m ? (uint32_t)a[li] : kInf, l1 = li + 1 < m ? (uint32_t)a[li + 1] : kInf;
+            const uint32_t q0 = qi < qn ? (uint32_t)a[qi] : kInf, q1 = qi + 1 < qn ? (uint32_t)a[qi + 1] : kInf;
+            // first = smaller head (leaf on ties), second = smaller of the heads left
+            const uint32_t tl = l0 <= q0 ? 1u : 0u;
+            const uint32_t first = tl ? l0 : q0, nl = tl ? l1 : l0, nq = tl ? q0 : q1;
+            const uint32_t t2 = nl <= nq ? 1u : 0u;
+            const uint32_t sum = first + (t2 ? nl : nq);
+            li += tl + t2; qi += 2u - tl - t2;
+            cost += sum;
+            a[qn++] = (uint16_t)sum;                    // <= 16384: the block's symbol count
         }
-        cost += sum;
-        if (lane == 0) queue[qn] = sum;
-        if (lane == qn - qbase) qw = sum;               // qn - qbase >= 64: no lane, the refill picks it up from LDS
-        qn++;
     }
     return cost;
 }
 
+constexpr uint32_t kCostLaneWords = 161;   // 160 words of sorted counts per lane, odd stride against bank conflicts
+__global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ probes, uint32_t n_blocks_total) {
+    __shared__ uint32_t arr[64 * kCostLaneWords];
+    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u;
+    const uint32_t g = g0 + lane;
+    const bool live = g < n_blocks_total && probes[g].state == 1;
+    uint32_t m_l = 0, m_d = 0;
+    if (live) { m_l = probes[g].m_l; m_d = probes[g].m_d; }
+    // stage the sorted counts of every probed block of this wave: lane-private rows, coalesced copy
+    for (uint32_t j = 0; j < 64; j++) {
+        const uint32_t ml = __shfl(m_l, j), md = __shfl(m_d, j);
+        if (ml == 0) continue;                           // not probed (a probed block has at least the EOB... and one symbol)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(probes[g0 + j].lit);
+        uint32_t* dst = arr + j * kCostLaneWords;
+        for (uint32_t w = lane; w < (ml + 1u) / 2u; w += 64) dst[w] = src[w];
+        if (lane < (md + 1u) / 2u) dst[144 + lane] = src[144 + lane];
+    }
+    __syncthreads();
+    uint32_t max_l = m_l, max_d = m_d;
+    for (uint32_t d = 32; d >= 1; d >>= 1) { max_l = max(max_l, (uint32_t)__shfl_xor(max_l, d)); max_d = max(max_d, (uint32_t)__shfl_xor(max_d, d)); }
+    uint16_t* row = reinterpret_cast<uint16_t*>(arr + lane * kCostLaneWords);
+    const uint32_t hl = lane_huffman_cost(row, m_l, max_l);
+    const uint32_t hd = lane_huffman_cost(row + 288, m_d, max_d);
+    if (live) {
+        const StoredProbe pr{probes[g].static_len, probes[g].extra_bits, probes[g].used};
+        if (stored_is_certain(pr, hl, hd, probes[g].stored_len, true)) probes[g].state = 2;
+    }
+}
+
 __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
-                                                  BlockOut* __restrict__ plans) {
+                                                  const BlockProbe* __restrict__ probes, BlockOut* __restrict__ plans) {
     __shared__ TreeScratch ts;
     __shared__ BlockCodes bc;
     __shared__ uint32_t hdr[kHdrWords];
     __shared__ uint16_t lf[kLCodes], df[kDCodes];
-    __shared__ uint16_t sorted[kLCodes + 2];
-    __shared__ __attribute__((aligned(16))) uint32_t keys[kSortKeys];
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
     if (b >= info[chunk].n_blocks) return;
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
     BlockOut* bo = plans + (size_t)chunk * kMaxBlocks + b;
+    const uint32_t last = b + 1 == info[chunk].n_blocks;
+    if (probes[blockIdx.x].state == 2) {                // the shortcut settled it: codes are never read for stored blocks
+        if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
     if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) hdr[i] = 0;
     __syncthreads();
-    const uint32_t last = b + 1 == info[chunk].n_blocks;
     const uint32_t stored_len = bi->end - bi->start;
     const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
-
-    // ---- shortcut: is "stored" already certain?
-    uint32_t m_l = 0, m_d = 0, certain = 0;
-    if (stored_ok && stored_len > 0) {
-        uint32_t* queue = ts.heap;                      // scratch not yet in use
-        // exact static_len / extra bits / used codes: five symbols per lane, wave reduction
-        StoredProbe pr{0, 0, 0};
-        for (uint32_t n = threadIdx.x; n < kLCodes + kDCodes; n += 64) {
-            const bool lit = n < kLCodes;
-            const uint32_t f = lit ? lf[n] : df[n - kLCodes];
-            if (!f) continue;
-            const uint32_t x = lit ? (n >= 257u ? length_extra_bits(n - 257u) : 0u) : dist_extra_bits(n - kLCodes);
-            pr.static_len += f * ((lit ? static_lit_len(n) : 5u) + x); pr.extra_bits += f * x; pr.used++;
-        }
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            pr.static_len += __shfl_xor(pr.static_len, d); pr.extra_bits += __shfl_xor(pr.extra_bits, d); pr.used += __shfl_xor(pr.used, d);
-        }
-        wave_rank_sort(lf, kLCodes, keys, sorted, &m_l);
-        __syncthreads();
-        const uint32_t hl = huffman_cost_wave(sorted, m_l, queue);
-        __syncthreads();
-        wave_rank_sort(df, kDCodes, keys, sorted, &m_d);
-        __syncthreads();
-        const uint32_t hd = huffman_cost_wave(sorted, m_d, queue);
-        certain = stored_is_certain(pr, hl, hd, stored_len, stored_ok) ? 1u : 0u;
-        certain = __builtin_amdgcn_readfirstlane(certain);
-    }
-    if (certain) {
-        if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
-        return;   // codes are never read for stored blocks
-    }
 
     if (threadIdx.x == 0) {
         BlockPlan bp = plan_block(ts, lf, df, stored_len, stored_ok, last, bc, hdr);
@@ -1190,7 +1226,9 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst, a.m32,
                        a.info, a.blocks);
     if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
-    hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.plans);
+    hipLaunchKernelGGL(plan_probe_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes);
+    hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + 63u) / 64u), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
+    hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
                        a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len);
