@@ -304,10 +304,19 @@ ZWZ_HD StoredProbe probe_block(const uint16_t* lfreq, const uint16_t* dfreq) {
     return r;
 }
 
-ZWZ_HD bool stored_is_certain(const StoredProbe& pr, uint32_t huff_lit, uint32_t huff_dist, uint32_t stored_len, bool stored_ok) {
-    if (!stored_ok) return false;
+// What the lower bound settles without building zlib's trees (_tr_flush_block's decision):
+//   stored  iff stored_ok and stored_len + 4 <= min(opt_lenb, static_lenb)
+//   static  iff not stored and static_lenb <= opt_lenb
+// With opt_lbb <= opt_lenb: "stored" is certain when stored_len + 4 clears min(opt_lbb, static_lenb);
+// "static" is certain when static_lenb <= opt_lbb and stored is ruled out (tiny blocks: the 14+12 bit
+// dynamic header alone outweighs them).  Returns kShortNone when the exact trees are needed.
+enum : uint32_t { kShortNone = 0, kShortStored = 1, kShortStatic = 2 };
+ZWZ_HD uint32_t shortcut_type(const StoredProbe& pr, uint32_t huff_lit, uint32_t huff_dist, uint32_t stored_len, bool stored_ok) {
     const uint32_t opt_lb = huff_lit + huff_dist + pr.extra_bits + 14u + 12u + (pr.used + 5u) / 6u;
-    return stored_len + 4u <= ((opt_lb + 10u) >> 3) && stored_len + 4u <= ((pr.static_len + 10u) >> 3);
+    const uint32_t opt_lbb = (opt_lb + 10u) >> 3, static_lenb = (pr.static_len + 10u) >> 3;
+    if (stored_ok && stored_len + 4u <= opt_lbb && stored_len + 4u <= static_lenb) return kShortStored;
+    if (static_lenb <= opt_lbb) return kShortStatic;     // min(opt_lenb, static_lenb) = static_lenb, and stored_len + 4 > static_lenb or stored not allowed
+    return kShortNone;
 }
 
 // Bits of one symbol under a block's codes, LSB-first.  Literal: entry == 0, lit = byte.

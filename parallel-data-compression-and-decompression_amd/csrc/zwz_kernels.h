@@ -45,11 +45,12 @@ struct BlockOut {
 };
 
 // Stored-block shortcut, stage 1 -> stage 2: a block's histograms sorted ascending, plus the exact
-// sums the lower bound needs (huff_core.h: stored_is_certain).
+// sums the lower bound needs (huff_core.h: shortcut_type).
+enum : uint32_t { kProbeNone = 0, kProbeOpen = 1, kProbeStored = 2, kProbeStatic = 3 };
 struct BlockProbe {
     uint32_t static_len, extra_bits, used, m_l, m_d, stored_len;
-    uint32_t state;               // 0: no shortcut (build the trees), 1: probe filled in, 2: "stored" is certain
-    uint32_t pad;
+    uint32_t state;               // kProbe*: not a block / probed, undecided / "stored" certain / "static" certain
+    uint32_t stored_ok;
     uint16_t lit[288];            // ascending non-zero literal/length counts, m_l of them
     uint16_t dist[32];            // ascending non-zero distance counts, m_d of them
 };

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 //   plan_probe (one wave per block): the stored-block shortcut's parallel half -- exact static_len /
 //       extra bits / used codes, and both histograms rank-sorted ascending -> BlockProbe.
 //   plan_cost  (one LANE per block): the optimal Huffman cost of the sorted counts by two-queue
-//       merge, 64 blocks per wave, then huff_core.h's stored_is_certain.  The merge is a chain of
+//       merge, 64 blocks per wave, then huff_core.h's shortcut_type.  The merge is a chain of
 //       ~m dependent steps; a wave per block spends them on one lane (and on the CU's one scalar
 //       issue slot per cycle when written with readlanes -- measured 560 cycles per step with 20
 //       such waves on a CU), a lane per block runs 64 chains in each instruction.
@@ -613,13 +613,9 @@ __global__ __launch_bounds__(64) void plan_probe_kernel(const ChunkInfo* __restr
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
     BlockProbe* pb = probes + blockIdx.x;
     const BlockInfo* bi = blocks + blockIdx.x;
-    uint32_t stored_len = 0;
-    bool probe = b < info[chunk].n_blocks;
-    if (probe) {
-        stored_len = bi->end - bi->start;
-        probe = stored_len > 0 && !(bi->flush_pos >= kSlidePos && bi->start < kWSize);   // "stored" must be allowed at all
-    }
-    if (!probe) { if (threadIdx.x == 0) pb->state = 0; return; }
+    if (b >= info[chunk].n_blocks) { if (threadIdx.x == 0) pb->state = kProbeNone; return; }
+    const uint32_t stored_len = bi->end - bi->start;
+    const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
     for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
     if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
     __syncthreads();
@@ -640,7 +636,7 @@ __global__ __launch_bounds__(64) void plan_probe_kernel(const ChunkInfo* __restr
     const uint32_t m_d = wave_rank_sort(df, kDCodes, keys, pb->dist);
     if (threadIdx.x == 0) {
         pb->static_len = pr.static_len; pb->extra_bits = pr.extra_bits; pb->used = pr.used;
-        pb->m_l = m_l; pb->m_d = m_d; pb->stored_len = stored_len; pb->state = 1;
+        pb->m_l = m_l; pb->m_d = m_d; pb->stored_len = stored_len; pb->stored_ok = stored_ok; pb->state = kProbeOpen;
     }
 }
 
@@ -673,13 +669,13 @@ __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ 
     __shared__ uint32_t arr[64 * kCostLaneWords];
     const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u;
     const uint32_t g = g0 + lane;
-    const bool live = g < n_blocks_total && probes[g].state == 1;
+    const bool live = g < n_blocks_total && probes[g].state == kProbeOpen;
     uint32_t m_l = 0, m_d = 0;
     if (live) { m_l = probes[g].m_l; m_d = probes[g].m_d; }
     // stage the sorted counts of every probed block of this wave: lane-private rows, coalesced copy
     for (uint32_t j = 0; j < 64; j++) {
         const uint32_t ml = __shfl(m_l, j), md = __shfl(m_d, j);
-        if (ml == 0) continue;                           // not probed (a probed block has at least the EOB... and one symbol)
+        if (ml == 0) continue;                           // not a block (a block counts at least its end-of-block symbol)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(probes[g0 + j].lit);
         uint32_t* dst = arr + j * kCostLaneWords;
         for (uint32_t w = lane; w < (ml + 1u) / 2u; w += 64) dst[w] = src[w];
@@ -693,7 +689,8 @@ __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ 
     const uint32_t hd = lane_huffman_cost(row + 288, m_d, max_d);
     if (live) {
         const StoredProbe pr{probes[g].static_len, probes[g].extra_bits, probes[g].used};
-        if (stored_is_certain(pr, hl, hd, probes[g].stored_len, true)) probes[g].state = 2;
+        const uint32_t t = shortcut_type(pr, hl, hd, probes[g].stored_len, probes[g].stored_ok != 0);
+        if (t != kShortNone) probes[g].state = t == kShortStored ? kProbeStored : kProbeStatic;
     }
 }
 
@@ -708,8 +705,18 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
     BlockOut* bo = plans + (size_t)chunk * kMaxBlocks + b;
     const uint32_t last = b + 1 == info[chunk].n_blocks;
-    if (probes[blockIdx.x].state == 2) {                // the shortcut settled it: codes are never read for stored blocks
+    const uint32_t settled = probes[blockIdx.x].state;
+    if (settled == kProbeStored) {                      // codes are never read for stored blocks
         if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
+        return;
+    }
+    if (settled == kProbeStatic) {                      // the static codes, written out so the encoder needs no special case
+        if (threadIdx.x == 0) {
+            bo->type = kStatic; bo->hdr_bits = 3; bo->body_bits = probes[blockIdx.x].static_len; bo->hdr[0] = (1u << 1) + last;
+            bo->eob_len = static_lit_len(256); bo->eob_code = static_lit_code(256);
+        }
+        for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) { bo->llen[i] = (uint8_t)static_lit_len(i); bo->lcode[i] = (uint16_t)static_lit_code(i); }
+        if (threadIdx.x < kDCodes) { bo->dlen[threadIdx.x] = 5; bo->dcode[threadIdx.x] = (uint16_t)bit_reverse(threadIdx.x, 5); }
         return;
     }
     for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];

@@ -13,8 +13,9 @@
 
 using namespace zwz;
 
-static uint64_t g_shortcut_hits = 0;
+static uint64_t g_shortcut_hits = 0, g_static_hits = 0;
 extern "C" uint64_t emu_shortcut_hits() { return g_shortcut_hits; }
+extern "C" uint64_t emu_static_shortcut_hits() { return g_static_hits; }
 
 namespace {
 struct Out {
@@ -90,8 +91,8 @@ extern "C" uint32_t emu_chunk_stream(const uint8_t* in, uint32_t L, uint8_t* out
         uint32_t bs = blk_start[b], be = blk_start[b + 1];
         uint32_t last = b + 1 == nblocks;
         bool stored_ok = !(flush_pos[b] >= kSlidePos && bs < kWSize);
-        // the stored-block shortcut must never contradict zlib's exact decision
-        bool certain = false;
+        // the shortcut must never contradict zlib's exact decision
+        uint32_t certain = kShortNone;
         {
             std::vector<uint16_t> sl, sd;
             for (uint16_t f : lf[b]) if (f) sl.push_back(f);
@@ -100,11 +101,11 @@ extern "C" uint32_t emu_chunk_stream(const uint8_t* in, uint32_t L, uint8_t* out
             std::vector<uint32_t> q(kLCodes + 2);
             uint32_t hl = huffman_cost_sorted(sl.data(), (uint32_t)sl.size(), q.data());
             uint32_t hd = huffman_cost_sorted(sd.data(), (uint32_t)sd.size(), q.data());
-            certain = be > bs && stored_is_certain(probe_block(lf[b].data(), df[b].data()), hl, hd, be - bs, stored_ok);
-            g_shortcut_hits += certain;
+            certain = shortcut_type(probe_block(lf[b].data(), df[b].data()), hl, hd, be - bs, stored_ok);
+            g_shortcut_hits += certain == kShortStored; g_static_hits += certain == kShortStatic;
         }
         BlockPlan bp = plan_block(ts, lf[b].data(), df[b].data(), be - bs, stored_ok, last, bc, hdr);
-        if (certain && bp.type != kStored) return 0xfffffffeu;
+        if ((certain == kShortStored && bp.type != kStored) || (certain == kShortStatic && bp.type != kStatic)) return 0xfffffffeu;
         for (uint32_t i = 0; i < bp.hdr_bits; i += 32) {
             uint32_t n = bp.hdr_bits - i < 32 ? bp.hdr_bits - i : 32;
             o.put(hdr[i >> 5] & (n == 32 ? 0xffffffffu : ((1u << n) - 1)), n);
