@@ -508,42 +508,58 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
     if (tid == 0) s_start[0] = 0;
     __syncthreads();
 
-    // histograms, position-parallel (coalesced byte / record reads)
+    // histograms: a thread takes 16 consecutive positions at a time -- one 16-byte load of input and
+    // a 16-bit slice of each mask -- four such groups per trip with every load of the trip issued
+    // before the first use.  (One byte per thread per load left the loop waiting out ~200 global
+    // round trips per chunk.)  A position's block is the number of block starts at or before it.
     const uint8_t* data = in + in_off[chunk];
     const uint2* ent = entries + (size_t)chunk * kEntryStride;
-    // four positions per thread per trip, all loads of a trip issued before the first use (one
-    // position per trip left the loop waiting out a global-load round trip each time); a position's
-    // block is the number of block starts at or before it
+    const uint4* d4 = reinterpret_cast<const uint4*>(data);          // readable up to L rounded up to 16 (API contract)
     const uint32_t c1 = ci.n_blocks > 1 ? s_start[1] : 0xffffffffu, c2 = ci.n_blocks > 2 ? s_start[2] : 0xffffffffu;
     const uint32_t c3 = ci.n_blocks > 3 ? s_start[3] : 0xffffffffu, c4 = ci.n_blocks > 4 ? s_start[4] : 0xffffffffu;
-    for (uint32_t p0 = tid; p0 < (nwords << 6); p0 += 4 * kBlockifyThreads) {
-        uint32_t byte[4]; uint64_t mw[4], sw3[4]; uint2 e2[4]; bool isym[4];
+    auto block_of = [&](uint32_t p) { return (uint32_t)(p >= c1) + (uint32_t)(p >= c2) + (uint32_t)(p >= c3) + (uint32_t)(p >= c4); };
+    const uint32_t ngroups = (L + 15u) >> 4;
+    for (uint32_t g0 = tid; g0 < ngroups; g0 += 4 * kBlockifyThreads) {
+        uint4 bytes[4]; uint32_t lits[4], mats[4], sel[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t p = p0 + u * kBlockifyThreads, wi = p >> 6;
-            const bool in = wi < nwords;
-            isym[u] = in && ((s_sym[in ? wi : 0] >> (p & 63)) & 1ull);
-            byte[u] = (in && p < L) ? data[p] : 0u;
-            mw[u] = in ? gmst[wi] : 0ull;
-            sw3[u] = in ? gm32[wi] : 0ull;
+            const uint32_t g = g0 + u * kBlockifyThreads;
+            const bool in = g < ngroups;
+            const uint32_t wi = in ? g >> 2 : 0u, sh = (g & 3u) * 16u;
+            bytes[u] = in ? d4[g] : make_uint4(0, 0, 0, 0);
+            const uint32_t sy = in ? (uint32_t)(s_sym[wi] >> sh) & 0xffffu : 0u;
+            const uint32_t mt = in ? (uint32_t)(gmst[wi] >> sh) & 0xffffu : 0u;
+            sel[u] = in ? (uint32_t)(gm32[wi] >> sh) & 0xffffu : 0u;
+            mats[u] = sy & mt; lits[u] = sy & ~mt;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t p = p0 + u * kBlockifyThreads;
-            e2[u] = make_uint2(0u, 0u);
-            if (isym[u] && ((mw[u] >> (p & 63)) & 1ull)) e2[u] = ent[p];
-        }
+            const uint32_t pg = (g0 + u * kBlockifyThreads) << 4;
+            const uint32_t b_lo = block_of(pg), b_hi = block_of(pg + 15u);
+            const uint32_t wd[4] = {bytes[u].x, bytes[u].y, bytes[u].z, bytes[u].w};
+            if (lits[u]) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            if (!isym[u]) continue;
-            const uint32_t p = p0 + u * kBlockifyThreads, bit = p & 63;
-            const uint32_t bk = (uint32_t)(p >= c1) + (uint32_t)(p >= c2) + (uint32_t)(p >= c3) + (uint32_t)(p >= c4);
-            if ((mw[u] >> bit) & 1ull) {
-                const uint32_t e = ((sw3[u] >> bit) & 1ull) ? e2[u].y : e2[u].x;
-                atomicAdd(&s_hist[bk][257u + length_code(entry_len(e) - kMinMatch)], 1u);
-                atomicAdd(&s_hist[bk][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
-            } else {
-                atomicAdd(&s_hist[bk][byte[u]], 1u);
+                for (uint32_t j = 0; j < 16; j++) {
+                    if (!((lits[u] >> j) & 1u)) continue;
+                    const uint32_t bk = b_lo == b_hi ? b_lo : block_of(pg + j);
+                    atomicAdd(&s_hist[bk][(wd[j >> 2] >> ((j & 3u) * 8u)) & 0xffu], 1u);
+                }
+            }
+            uint32_t mm = mats[u];
+            while (mm) {                                 // match records, four loads in flight
+                uint32_t q[4]; uint2 e2[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) { q[k] = mm ? pg + (uint32_t)__builtin_ctz(mm) : 0xffffffffu; mm &= mm - 1u; }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) e2[k] = ent[q[k] != 0xffffffffu ? q[k] : pg];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (q[k] == 0xffffffffu) continue;
+                    const uint32_t e = ((sel[u] >> (q[k] & 15u)) & 1u) ? e2[k].y : e2[k].x;
+                    const uint32_t bk = b_lo == b_hi ? b_lo : block_of(q[k]);
+                    atomicAdd(&s_hist[bk][257u + length_code(entry_len(e) - kMinMatch)], 1u);
+                    atomicAdd(&s_hist[bk][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
+                }
             }
         }
     }
