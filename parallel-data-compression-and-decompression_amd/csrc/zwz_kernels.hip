@@ -768,6 +768,82 @@ static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpo
     if (w + 2 < kOutWords && hi) atomicOr(&out[w + 2], hi);
 }
 
+// An incompressible chunk: every block is stored, so the stream is the input with a 2-byte zlib
+// header, a 5-byte header in front of each block and the Adler-32 behind.  No staging: one pass
+// over the input for the checksum (v_dot4 sums four bytes per instruction), one pass that writes
+// whole output dwords straight to HBM, each from one unaligned 4-byte read of the input except
+// the handful of dwords that touch a header.
+static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __restrict__ data, uint32_t L, uint32_t n_blocks,
+                                                           const BlockInfo* __restrict__ bi, uint32_t* __restrict__ gout,
+                                                           uint32_t* __restrict__ out_len_slot) {
+    __shared__ uint32_t s_hb[kMaxBlocks + 1], s_st[kMaxBlocks + 1];   // stream offset of each block header; its first input byte
+    __shared__ uint32_t s_a[kEncodeThreads / 64], s_adler_be;
+    __shared__ unsigned long long s_b[kEncodeThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t hb = 2;
+        for (uint32_t b = 0; b < n_blocks; b++) { s_hb[b] = hb; s_st[b] = bi[b].start; hb += 5u + (bi[b].end - bi[b].start); }
+        for (uint32_t b = n_blocks; b <= kMaxBlocks; b++) { s_hb[b] = hb; s_st[b] = L; }   // s_hb[n_blocks] = where the Adler-32 goes
+    }
+    // Adler-32: a = 1 + sum d_i, b = L + sum (L - i) d_i  (mod 65521); 16 dwords per thread, all in flight
+    const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
+    uint32_t w[16];
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+        const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+        w[u] = i < L ? d32[i >> 2] : 0u;                  // slot readable to L rounded up to 16
+    }
+    uint32_t a_sum = 0; unsigned long long b_sum = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+        const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+        uint32_t x = w[u];
+        if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
+        const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
+        a_sum += sum;
+        b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
+    }
+    for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
+    if (lane_id() == 0) { s_a[tid >> 6] = a_sum; s_b[tid >> 6] = b_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long a = 1, b = L;
+        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_a[i]; b += s_b[i]; }
+        s_adler_be = __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
+        const uint32_t total = s_hb[n_blocks] + 4u;
+        *out_len_slot = total < kChunk ? total : kChunk;
+    }
+    __syncthreads();
+    const uint32_t total = s_hb[n_blocks] + 4u, n_out = total < kChunk ? total : kChunk;
+    const uint32_t h1 = s_hb[1], h2 = s_hb[2], h3 = s_hb[3], h4 = s_hb[4], h_end = s_hb[n_blocks], adler_be = s_adler_be;
+    auto block_at = [&](uint32_t x) { return (uint32_t)(x >= h1) + (uint32_t)(x >= h2) + (uint32_t)(x >= h3) + (uint32_t)(x >= h4); };   // unused slots hold h_end
+    auto byte_at = [&](uint32_t x) -> uint32_t {
+        if (x < 2u) return x ? 0x9cu : 0x78u;
+        if (x >= h_end) return x - h_end < 4u ? (adler_be >> (8u * (x - h_end))) & 0xffu : 0u;
+        uint32_t b = block_at(x);
+        if (b >= n_blocks) b = n_blocks - 1u;
+        const uint32_t off = x - s_hb[b], len = s_hb[b + 1] - s_hb[b] - 5u;
+        if (off == 0u) return b + 1u == n_blocks ? 1u : 0u;
+        if (off < 5u) { const uint32_t f = (len & 0xffffu) | ((~len & 0xffffu) << 16); return (f >> (8u * (off - 1u))) & 0xffu; }
+        return data[s_st[b] + off - 5u];
+    };
+    for (uint32_t o4 = tid; o4 < ((n_out + 3u) >> 2); o4 += kEncodeThreads) {
+        const uint32_t o = o4 * 4u;
+        uint32_t b = block_at(o);
+        if (b >= n_blocks) b = n_blocks - 1u;
+        const uint32_t lo = s_hb[b] + 5u, hi = s_hb[b + 1];
+        uint32_t v;
+        if (o >= lo && o + 4u <= hi && hi <= h_end) {
+            const uint32_t p = s_st[b] + (o - lo);
+            const uint32_t* q = d32 + (p >> 2);
+            v = (p & 3u) ? __builtin_amdgcn_alignbyte(q[1], q[0], p & 3u) : q[0];
+        } else {
+            v = byte_at(o) | byte_at(o + 1u) << 8 | byte_at(o + 2u) << 16 | byte_at(o + 3u) << 24;
+        }
+        gout[o4] = v;
+    }
+}
+
 __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
@@ -799,6 +875,14 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
     const uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
 
+    {   // wave-uniform: are all blocks stored?
+        bool all_stored = ci.n_blocks > 0;
+        for (uint32_t b = 0; b < ci.n_blocks; b++) all_stored = all_stored && bo[b].type == kStored;
+        if (all_stored) {
+            encode_stored_chunk(data, L, ci.n_blocks, bi, reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
+            return;
+        }
+    }
     for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
     // symbol ranks again (cheaper to recompute than to round-trip through HBM)
     {
@@ -864,37 +948,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
     uint8_t* s_out8 = reinterpret_cast<uint8_t*>(s_out);
-    bool all_stored = true;
-    for (uint32_t b = 0; b < ci.n_blocks; b++) all_stored = all_stored && s_blk[b].type == kStored;
-    if (all_stored) {
-        // incompressible chunk: every block is a byte copy behind a 5-byte header; no code lengths,
-        // no scan, no barriers -- four input bytes per thread per trip
-        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
-        const uint32_t Lr = (L + 15u) & ~15u;                         // slot readable to the next multiple of 16
-        uint32_t w[16];
-#pragma unroll
-        for (uint32_t u = 0; u < 16; u++) {                           // the chunk's 16 dwords of this thread, all in flight
-            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-            w[u] = i < Lr ? d32[i >> 2] : 0u;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 16; u++) {
-            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-            if (i >= L) break;
-            uint32_t blk = 0;
-            while (blk + 1 < ci.n_blocks && i >= s_blk[blk].end) blk++;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t p = i + j;
-                if (p >= L) break;
-                if (p >= s_blk[blk].end) blk++;
-                const uint32_t byte = (w[u] >> (8 * j)) & 0xffu;
-                a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
-                const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
-                if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
-            }
-        }
-    } else {
+    {
         // Symbols.  Wave w owns the contiguous positions [4096 w, 4096 w + 4096): a first pass adds up
         // its code lengths, one barrier turns the 16 wave totals into start offsets, and the second
         // pass packs bits with wave-local scans only (a barrier per 1024 positions kept the single
