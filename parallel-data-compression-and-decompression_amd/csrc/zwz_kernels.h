@@ -11,7 +11,8 @@ namespace zwz {
 // Per-chunk strides of the intermediates (elements).  Everything is indexed [chunk][position].
 constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
 constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
-constexpr uint32_t kLinksLdsBytes = 65536 + 4096 + 16;              // head table + input ring + mirror
+constexpr uint32_t kLinksThreads = 128;                            // one inserter wave + one feeder wave per chunk
+constexpr uint32_t kLinksLdsBytes = 65536 + 16 + 2 * 2048 * 2 + 256;  // head table + dummy slot + two hash/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)

@@ -30,84 +30,184 @@ static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_
 
 // ------------------------------------------------------------------------------------------------
 // lz_links: link[p] = newest position q < p with hash3(q) == hash3(p), 0 if none (zlib NIL).
-// One wave walks the chunk 64 positions at a time; the 64 KiB head table lives in LDS, next to a
-// 4 KiB ring of input bytes that is refilled 2 KiB at a time, one refill ahead (the global loads
-// of a refill are issued 32 steps before they are needed, so no step waits on HBM).
-// A step's critical path is one LDS round trip: head read -> write -> read-back (collision check).
-constexpr uint32_t kLinksHalf = 2048, kLinksRing = 2 * kLinksHalf;
+// The chain insert is sequential in the position: one wave walks the chunk 64 positions a step with
+// the 64 KiB head table in LDS -- and a lone wave issues an instruction every ~6 cycles, so a step
+// costs what its instruction count says (the first version: ~45 instructions, 270 cycles, with two
+// of a CU's four SIMDs idle because two head tables fill its LDS).  So the work of a step is split
+// over two waves of a workgroup, on two SIMDs:
+//   wave 1 (feeder): input bytes -> hash values of the next 2048 positions into an LDS buffer, and
+//           the finished links of the previous 2048 positions out of that buffer to HBM, both as
+//           16-byte vectors;
+//   wave 0 (inserter): per step one hash read, the head read / write / read-back, the collision
+//           check, one link write -- ~15 instructions.
+// The two meet at a barrier every 2048 positions (two buffers alternate).  Positions past the last
+// trigram get the out-of-range hash value 32768, whose "bucket" is a dummy slot behind the table:
+// the inserter needs no validity logic, the feeder zeroes those links on the way out.
+//
+// The inserter's steps are software-pipelined by hand: the three LDS operations of step s+1 are
+// issued before step s's read-back is looked at.  LDS returns in order, so "step s is back" is the
+// counter threshold lgkmcnt(3); the compiler's own wait insertion drains to 0 at loop headers, so
+// these LDS reads are issued from inline asm and waited for by hand.  What keeps that sound:
+//   * every step issues exactly three operations, preceded by the read of the next step's hashes;
+//   * a loaded register is not read before the wait that names it ("+v" ties the two);
+//   * two named register sets alternate, so no value crosses a copy while in flight.
+// A collision inside step s (lanes sharing a hash: one store wins, all read the old head) is then
+// repaired one step late, which adds two cases to the repair: lanes of step s+1 with the same hash
+// have read an arbitrary peer of s (they get the newest one, through `patch`), and the bucket is
+// rewritten only if s+1 did not already store a newer position in it.
+constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
+constexpr uint32_t kLinksNoHash = 32768;           // "hash" of a position without a trigram
 
-__global__ __launch_bounds__(64) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
-                                                      const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links) {
+__global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                 const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
-    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries
-    uint8_t* ring = reinterpret_cast<uint8_t*>(head + 32768);                // kLinksRing + 16 mirror bytes
-    const uint32_t chunk = blockIdx.x, lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries + the dummy slot
+    uint16_t* hbuf = head + 32768 + 8;                                       // 2 x kLinksBlock: hashes in, links out
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t L = in_len[chunk];
+    if (L == 0) return;
     const uint8_t* data = in + in_off[chunk];                                // 16-byte aligned (API contract)
     uint16_t* lk = links + (size_t)chunk * kLinkStride;
+    const uint32_t Lr = (L + 15u) & ~15u;                                    // the slot is readable this far
+    const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
 
     uint4* h4 = reinterpret_cast<uint4*>(head);
-    for (uint32_t i = lane; i < 65536u / 16u; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < (65536u + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
 
-    // half h of the input = bytes [2048 h, 2048 h + 2048): 32 bytes per lane as two uint4
-    const uint32_t n_half = (L + kLinksHalf - 1) / kLinksHalf;
-    auto fetch_half = [&](uint32_t h, uint4& a, uint4& b) {
-        const uint32_t o = h * kLinksHalf + lane * 32u;
-        a = make_uint4(0, 0, 0, 0); b = a;
-        // whole 16-byte vectors up to the chunk length rounded up to 16 (API contract: the slot is
-        // readable that far; bytes past L never reach a valid hash)
-        const uint32_t R = (L + 15u) & ~15u;
+    // ---- feeder
+    auto hash_block = [&](uint32_t k) {            // hashes of positions [2048 k, 2048 k + 2048): 32 per lane
+        const uint32_t o = k * kLinksBlock + lane * 32u;
+        uint32_t w[9];
         const uint4* g = reinterpret_cast<const uint4*>(data + o);
-        if (o + 16u <= R) a = g[0];
-        if (o + 32u <= R) b = g[1];
-    };
-    auto store_half = [&](uint32_t h, const uint4& a, const uint4& b) {
-        uint4* r = reinterpret_cast<uint4*>(ring + (h & 1u) * kLinksHalf + lane * 32u);
-        r[0] = a; r[1] = b;
-        if ((h & 1u) == 0 && lane == 0) *reinterpret_cast<uint4*>(ring + kLinksRing) = a;   // wrap-around mirror
-    };
-    uint4 pa, pb;
-    fetch_half(0, pa, pb);
-    store_half(0, pa, pb);
-    fetch_half(1, pa, pb);
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-
-    uint32_t w_cur = load_u32(ring, lane);           // bytes p..p+3 of this step
-    for (uint32_t h = 0; h < n_half; h++) {
-        // ring holds half h; registers hold half h+1: publish it, then start loading half h+2
-        store_half(h + 1, pa, pb);
-        fetch_half(h + 2, pa, pb);
-        const uint32_t end = min(L, (h + 1) * kLinksHalf);
-        for (uint32_t base = h * kLinksHalf; base < end; base += 64) {
-            const uint32_t p = base + lane;
-            const uint32_t w_next = load_u32(ring, (p + 64u) & (kLinksRing - 1u));   // next step's bytes, off the critical path
-            const bool valid = p + kMinMatch <= L;
-            const uint32_t hsh = hash3(w_cur & 0xffu, (w_cur >> 8) & 0xffu, (w_cur >> 16) & 0xffu);
-            uint32_t prev = 0, rb = p;
-            if (valid) {
-                prev = head[hsh];
-                head[hsh] = (uint16_t)p;          // colliding lanes: one wins, fixed below
-                asm volatile("" ::: "memory");    // the read-back must see other lanes' stores: no forwarding
-                rb = head[hsh];
-            }
-            uint64_t dup = __ballot(valid && rb != p);
-            while (dup) {  // wave-uniform: one iteration per hash value shared inside this step
-                const uint32_t l = (uint32_t)__builtin_ctzll(dup);
-                const uint32_t hh = __builtin_amdgcn_readlane(hsh, l);
-                const uint64_t peers = __ballot(valid && hsh == hh);
-                if (valid && hsh == hh) {
-                    const uint64_t lower = peers & lanes_below();
-                    if (lower) prev = base + 63u - (uint32_t)__builtin_clzll(lower);
-                    if ((peers >> lane) == 1ull) head[hh] = (uint16_t)p;  // newest peer owns the bucket
-                }
-                dup &= ~peers;
-            }
-            lk[p] = (uint16_t)(valid ? prev : 0u);
-            w_cur = w_next;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a; uint32_t c = 0;
+        if (o + 16u <= Lr) a = g[0];
+        if (o + 32u <= Lr) b = g[1];
+        if (o + 36u <= Lr) c = reinterpret_cast<const uint32_t*>(data + o)[8];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c;
+        const uint32_t n_ok = L >= o + kMinMatch ? min(32u, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
+        uint32_t packed[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 32; i++) {
+            const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3u) : w[i >> 2];
+            uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
+            if (i >= n_ok) h = kLinksNoHash;
+            if (i & 1u) packed[i >> 1] |= h << 16; else packed[i >> 1] = h;
         }
+        uint4* dst = reinterpret_cast<uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) dst[j] = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
+    };
+    auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
+        const uint32_t o = k * kLinksBlock + lane * 32u;
+        const uint4* src = reinterpret_cast<const uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
+        uint4* dst = reinterpret_cast<uint4*>(lk + o);
+        const uint32_t n_ok = L >= o + kMinMatch ? min(32u, L - o - (kMinMatch - 1u)) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            uint4 v = src[j];
+            if (n_ok < 8u * j + 8u) {              // rare: the chunk's last positions
+                uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t i0 = 8u * j + 2u * q;
+                    if (i0 >= n_ok) e[q] = 0; else if (i0 + 1u >= n_ok) e[q] &= 0xffffu;
+                }
+                v = make_uint4(e[0], e[1], e[2], e[3]);
+            }
+            dst[j] = v;
+        }
+    };
+
+    // ---- inserter
+    struct Step { uint32_t p16, hsh, prev, rb, patch, slot; };
+    constexpr uint32_t kNoPatch = 0xffffffffu;
+    typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
+    const uint32_t head_a = (uint32_t)(uintptr_t)(lds_ptr)reinterpret_cast<uint8_t*>(head);   // LDS byte addresses
+    const uint32_t hbuf_a = head_a + 2u * (32768u + 8u);
+    auto read_hash = [&](uint32_t addr) -> uint32_t {
+        uint32_t h;
+        asm volatile("ds_read_u16 %0, %1" : "=v"(h) : "v"(addr) : "memory");
+        return h;
+    };
+    auto issue = [&](Step& S, uint32_t p16, uint32_t h, uint32_t slot) {
+        S.p16 = p16; S.hsh = h; S.patch = kNoPatch; S.slot = slot;
+        const uint32_t bucket = head_a + 2u * h;
+        // colliding lanes: one store wins, fixed at retire; the read-back sees the other lanes' stores
+        asm volatile("ds_read_u16 %0, %2\n\tds_write_b16 %2, %3\n\tds_read_u16 %1, %2"
+                     : "=&v"(S.prev), "=&v"(S.rb) : "v"(bucket), "v"(p16) : "memory");
+    };
+    auto retire = [&](Step& S, uint32_t& n_hsh, uint32_t& n_patch) {   // n_* = the step issued after S
+        uint32_t prev = S.patch != kNoPatch ? S.patch : S.prev;
+        uint64_t dup = __builtin_amdgcn_uicmp(S.rb, S.p16, 33 /* ICMP_NE */);
+        while (dup) {  // wave-uniform: one iteration per hash value shared inside step S
+            const uint32_t l = (uint32_t)__builtin_ctzll(dup);
+            const uint32_t hh = __builtin_amdgcn_readlane(S.hsh, l);
+            const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(S.p16) - __builtin_amdgcn_readfirstlane(lane);
+            const uint64_t peers = __builtin_amdgcn_uicmp(S.hsh, hh, 32 /* ICMP_EQ */);
+            const uint32_t top = 63u - (uint32_t)__builtin_clzll(peers), newest = p_lane0 + top;
+            if (S.hsh == hh) {
+                const uint64_t lower = peers & lanes_below();
+                if (lower) prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
+            }
+            const uint64_t after = __builtin_amdgcn_uicmp(n_hsh, hh, 32);
+            if (after == 0) { if (lane == top) head[hh] = (uint16_t)newest; }     // newest peer owns the bucket
+            else if (n_hsh == hh) n_patch = newest;                                // the next step's own repair overrides all but its lowest peer
+            dup &= ~peers;
+        }
+        asm volatile("ds_write_b16 %0, %1" :: "v"(S.slot), "v"(prev) : "memory");  // the link replaces the hash in the buffer
+    };
+    auto insert_block = [&](uint32_t k) {
+        const uint32_t first = k * kLinksBlock;
+        const uint32_t n_steps = (min(L, first + kLinksBlock) - first + 63u) / 64u;      // >= 1
+        uint32_t slot = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);                   // this lane's entry of the step to issue
+        uint32_t p16 = first + lane;
+        Step A, B;
+        uint32_t none_h = 0xffffffffu, none_p = kNoPatch;
+        uint32_t hx = read_hash(slot), hn = read_hash(slot + 128u);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hx), "+v"(hn) :: "memory");
+        issue(A, p16, hx, slot);
+        hx = hn;
+        uint32_t s = 0;
+        // A = step s in flight; hx = hashes of step s+1 (read, complete)
+        while (s + 2 < n_steps) {
+            hn = read_hash(slot + 256u);                                                  // step s+2
+            issue(B, p16 + 64u, hx, slot + 128u);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A.prev), "+v"(A.rb), "+v"(hn) :: "memory");
+            retire(A, B.hsh, B.patch);
+            hx = hn;
+            hn = read_hash(slot + 384u);                                                  // step s+3 (may lie past the block: unused then)
+            issue(A, p16 + 128u, hx, slot + 256u);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B.prev), "+v"(B.rb), "+v"(hn) :: "memory");
+            retire(B, A.hsh, A.patch);
+            hx = hn;
+            s += 2; p16 += 128u; slot += 256u;
+        }
+        if (s + 1 < n_steps) {
+            issue(B, p16 + 64u, hx, slot + 128u);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A.prev), "+v"(A.rb) :: "memory");
+            retire(A, B.hsh, B.patch);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B.prev), "+v"(B.rb) :: "memory");
+            retire(B, none_h, none_p);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A.prev), "+v"(A.rb) :: "memory");
+            retire(A, none_h, none_p);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    __syncthreads();
+    if (wave == 1) hash_block(0);
+    __syncthreads();
+    for (uint32_t k = 0; k < n_blocks; k++) {
+        if (wave == 0) insert_block(k);
+        else {
+            if (k >= 1) flush_block(k - 1);
+            if (k + 1 < n_blocks) hash_block(k + 1);
+        }
+        __syncthreads();
     }
+    if (wave == 1) flush_block(n_blocks - 1);
 }
 
 // Workgroup copy of n 16-byte vectors global -> LDS with eight loads in flight per thread.
@@ -1293,7 +1393,7 @@ hipError_t configure_kernels() {
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(64), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm);
