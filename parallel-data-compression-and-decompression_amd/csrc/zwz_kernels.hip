@@ -224,6 +224,104 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
     for (; i < n; i += T) dst[i] = src[i];
 }
 
+// lz_core.h's lz_search, restated for a whole wave: same candidates, same order, same records.
+// The chain walk is the framework's hottest loop.  Written per lane it compiles to ~32 instructions
+// per candidate, a third of them exec-mask bookkeeping for the per-lane exits; a predicated C++
+// version fared no better (every wave-uniform test became a select-and-compare pair).  So the
+// common path -- fetch the candidate's filter word and its link, compare, advance -- is 21
+// instructions of inline asm in which no lane ever leaves the loop: the candidate counter is
+// wave-uniform (an SGPR), `alive` is an SGPR lane mask, a lane whose chain has ended keeps
+// re-reading its last candidate, and the loop falls out to C++ only when some live lane's filter
+// word matches (worth a full comparison), the counter reaches its bound, or no lane is left.
+// (The filter word is two aligned reads and an alignbyte: one unaligned ds_read_b32 is legal on
+// gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.)
+static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
+                                                      bool active, uint32_t& e128, uint32_t& e32) {
+    typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
+    e128 = 0; e32 = 0;
+    const uint32_t lane = lane_id();
+    const uint32_t pp = p - org;                                   // inactive lanes pass any position of the tile
+    uint32_t cur = link[pp];
+    const bool start = active && p + kMinMatch <= L                // lookahead < 3: not inserted, not searched
+                       && cur != 0 && p - cur <= kMaxDist          // first candidate: distance <= MAX_DIST
+                       && !(p >= kSlidePos && cur <= kWSize);      // zlib's window has slid: <= 32768 reads as NIL
+    uint64_t alive = __builtin_amdgcn_ballot_w64(start);
+    if (alive == 0) return;
+    if (!start) cur = p;                                           // a readable stand-in
+    const uint32_t lookahead = L - p;
+    const uint32_t max_len = lookahead < kMaxMatch ? lookahead : kMaxMatch;
+    const uint32_t nice = lookahead < kNiceLen ? lookahead : kNiceLen;
+    const uint32_t limit = p > kMaxDist ? p - kMaxDist : 0;
+    constexpr uint32_t kNone = 0xffffffffu;
+    uint32_t best = kMinMatch - 1, best_pos = 0, snap = kNone;
+    uint32_t f_off = 0, f_mask = 0xffffffu;                        // see lz_search: the filter word
+    uint32_t scan_w = load_u32(data, pp) & f_mask;
+    const uint32_t data_a = (uint32_t)(uintptr_t)(lds_ptr)const_cast<uint8_t*>(data);                          // LDS byte addresses
+    const uint32_t link_a = (uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(link));
+    const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a - 2u * org);
+    uint32_t dbias = data_a - org + f_off;                         // filter word of candidate c: LDS byte cur + dbias
+    uint32_t n = 0;                                                // candidates examined: the same in every lane
+    // (a macro, not a lambda: with the SGPR operands captured by reference the backend fails with
+    // "illegal VGPR to SGPR copy")
+#define ZWZ_WALK(BOUND_)                                                                           \
+        for (;;) {                                                                                  \
+            uint64_t hit; uint32_t next, ta, tb, w0, w1, tl;                                        \
+            asm volatile(                                                                           \
+                "1:\n\t"                                                                            \
+                "v_add_u32 %[a], %[cur], %[dbias]\n\t"                                              \
+                "v_and_b32 %[b], -4, %[a]\n\t"                                                      \
+                "ds_read_b32 %[w0], %[b]\n\t"                                                       \
+                "ds_read_b32 %[w1], %[b] offset:4\n\t"                                              \
+                "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"                                      \
+                "ds_read_u16 %[next], %[l]\n\t"                                                     \
+                "v_and_b32 %[a], 3, %[a]\n\t"                                                       \
+                "s_waitcnt lgkmcnt(1)\n\t"                                                          \
+                "v_alignbyte_b32 %[w0], %[w1], %[w0], %[a]\n\t"                                     \
+                "v_and_b32 %[w0], %[w0], %[fmask]\n\t"                                              \
+                "v_cmp_eq_u32 vcc, %[w0], %[scan]\n\t"                                              \
+                "s_and_b64 %[hit], vcc, %[alive]\n\t"                                               \
+                "s_cbranch_scc1 2f\n\t"                                                             \
+                "s_add_u32 %[n], %[n], 1\n\t"                                                       \
+                "s_waitcnt lgkmcnt(0)\n\t"                                                          \
+                "v_cmp_gt_u32 vcc, %[next], %[limit]\n\t"                                           \
+                "s_and_b64 %[alive], %[alive], vcc\n\t"                                             \
+                "v_cndmask_b32 %[cur], %[cur], %[next], %[alive]\n\t"                               \
+                "s_cbranch_scc0 2f\n\t"                                                             \
+                "s_cmp_lt_u32 %[n], %[bound]\n\t"                                                   \
+                "s_cbranch_scc1 1b\n\t"                                                             \
+                "2:\n\t"                                                                            \
+                "s_waitcnt lgkmcnt(0)"                                                              \
+                : [cur] "+v"(cur), [alive] "+s"(alive), [n] "+s"(n), [hit] "=&s"(hit), [next] "=&v"(next), [a] "=&v"(ta), [b] "=&v"(tb),\
+                  [w0] "=&v"(w0), [w1] "=&v"(w1), [l] "=&v"(tl)                                     \
+                : [dbias] "v"(dbias), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(BOUND_)\
+                : "vcc", "scc", "memory");                                                          \
+            if (hit == 0) break;                                                                    \
+            if ((hit >> lane) & 1ull) {                                                             \
+                const uint32_t len = match_len_from(data, cur - org, pp, 0u, max_len);              \
+                if (len > best) {                                                                   \
+                    best = len; best_pos = cur;                                                     \
+                    if (len >= nice) next = 0;                                                      \
+                    else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a - org + f_off; }\
+                }                                                                                   \
+            }                                                                                       \
+            n++;                                                                                    \
+            alive &= __builtin_amdgcn_ballot_w64(next > limit);                                     \
+            if ((alive >> lane) & 1ull) cur = next;                                                 \
+            if (n >= BOUND_ || alive == 0) break;                                                   \
+        }
+    ZWZ_WALK(kShortChain)
+    if (n == kShortChain && alive != 0) {
+        if ((alive >> lane) & 1ull) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;   // what zlib's short chain returns
+        ZWZ_WALK(kMaxChain)
+    }
+#undef ZWZ_WALK
+    e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;
+    e32 = snap != kNone ? snap : e128;
+    // TOO_FAR: a minimum-length match further than 4096 back is dropped (deflate_slow)
+    if (entry_len(e128) == kMinMatch && entry_dist(e128) > kTooFar) e128 = 0;
+    if (entry_len(e32) == kMinMatch && entry_dist(e32) > kTooFar) e32 = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // lz_match: per-position match records.  One workgroup walks one chunk tile by tile (16 Ki positions
 // per tile) with the history zlib may look at -- bytes and links of the last 32506 positions --
@@ -347,11 +445,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             const uint32_t idx = tid + kk * kMatchThreads;
             if (__ballot(idx < npos) == 0) break;
             uint32_t e128 = 0, e32 = 0;
-            uint32_t p = 0;
-            if (idx < npos) {
-                p = ts + (sorted_order ? (uint32_t)perm[idx] : idx);
-                lz_search(sdata, slink, org, p, L, e128, e32);
-            }
+            uint32_t p = ts;
+            if (idx < npos) p = ts + (sorted_order ? (uint32_t)perm[idx] : idx);
+            lz_search_wave(sdata, slink, org, p, L, idx < npos, e128, e32);
             if (e128) {
                 ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
