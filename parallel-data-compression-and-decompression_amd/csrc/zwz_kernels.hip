@@ -255,7 +255,8 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
     constexpr uint32_t kNone = 0xffffffffu;
     uint32_t best = kMinMatch - 1, best_pos = 0, snap = kNone;
     uint32_t f_off = 0, f_mask = 0xffffffu;                        // see lz_search: the filter word
-    uint32_t scan_w = load_u32(data, pp) & f_mask;
+    const uint32_t scan0 = load_u32(data, pp), scan1 = load_u32(data, pp + 4u);   // the scan's first eight bytes: most full
+    uint32_t scan_w = scan0 & f_mask;                                             // comparisons end inside them, without a loop
     const uint32_t data_a = (uint32_t)(uintptr_t)(lds_ptr)const_cast<uint8_t*>(data);                          // LDS byte addresses
     const uint32_t link_a = (uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(link));
     const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a - 2u * org);
@@ -297,7 +298,11 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
                 : "vcc", "scc", "memory");                                                          \
             if (hit == 0) break;                                                                    \
             if ((hit >> lane) & 1ull) {                                                             \
-                const uint32_t len = match_len_from(data, cur - org, pp, 0u, max_len);              \
+                const uint32_t c_ = cur - org;                                                      \
+                const uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;\
+                uint32_t len = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;\
+                if (len == 8u) len = match_len_from(data, c_, pp, 8u, max_len);                     \
+                len = len < max_len ? len : max_len;                                                \
                 if (len > best) {                                                                   \
                     best = len; best_pos = cur;                                                     \
                     if (len >= nice) next = 0;                                                      \
