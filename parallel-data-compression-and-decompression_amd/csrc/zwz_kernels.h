@@ -17,7 +17,8 @@ constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
 constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
-constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + 4096;   // + has128 bits + bucket counts: 153280 of 163840
+constexpr uint32_t kMatchListBytes = 4096 + 10240;               // bucket counts of a sorted tile / per-wave work lists of a sparse tile
+constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163520 of 163840 (with 64 static)
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords

@@ -446,17 +446,66 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             }
             __syncthreads();
         }
-        for (uint32_t kk = 0; kk < 16u; kk++) {
-            const uint32_t idx = tid + kk * kMatchThreads;
-            if (__ballot(idx < npos) == 0) break;
+        auto search_and_store = [&](uint32_t p, bool active) {
             uint32_t e128 = 0, e32 = 0;
-            uint32_t p = ts;
-            if (idx < npos) p = ts + (sorted_order ? (uint32_t)perm[idx] : idx);
-            lz_search_wave(sdata, slink, org, p, L, idx < npos, e128, e32);
+            lz_search_wave(sdata, slink, org, p, L, active, e128, e32);
             if (e128) {
                 ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
             }
+        };
+        if (sorted_order) {
+            for (uint32_t kk = 0; kk < 16u; kk++) {
+                const uint32_t idx = tid + kk * kMatchThreads;
+                if (__ballot(idx < npos) == 0) break;
+                search_and_store(idx < npos ? ts + (uint32_t)perm[idx] : ts, idx < npos);
+            }
+        } else {
+            // Sparse tile (incompressible data: a position has one predecessor in range on average, most
+            // have none or one, a few have five).  In natural order a wave's trip lasts as long as its
+            // longest chain and most lanes idle (12% VALU lane utilisation on random bytes).  So a wave
+            // first screens its 1024 positions, four trips' reads in flight at a time:
+            //   no candidate in range              -> no record, done;
+            //   one candidate, trigram differs     -> no record, done (the walk would end on it);
+            //   anything else                      -> onto the wave's work list in LDS,
+            // and then runs the full search over the list, 64 entries a trip.  The list is bounded
+            // (kListCap entries): it is drained early whenever the next four trips might not fit.
+            constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 448
+            uint16_t* wl = s_cnt + wave * kListCap;
+            uint32_t nl = 0;                                                               // wave-uniform
+            auto drain = [&]() {
+                for (uint32_t i = lane; i - lane < nl; i += 64u) search_and_store(i < nl ? ts + (uint32_t)wl[i] : ts, i < nl);
+                nl = 0;
+            };
+            for (uint32_t k0 = 0; k0 < 16u; k0 += 4u) {
+                if (nl + 256u > kListCap) drain();
+                uint32_t q[4], l1[4], scan[4]; bool ok[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    q[u] = wave * 1024u + (k0 + u) * 64u + lane;
+                    const uint32_t p = ts + q[u];
+                    ok[u] = q[u] < npos && p + kMinMatch <= L;
+                    l1[u] = ok[u] ? (uint32_t)slink[p - org] : 0u;
+                    scan[u] = ok[u] ? load_u32(sdata, p - org) : 0u;
+                }
+                uint32_t l2[4], cw[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t p = ts + q[u];
+                    ok[u] = ok[u] && l1[u] != 0 && p - l1[u] <= kMaxDist && !(p >= kSlidePos && l1[u] <= kWSize);   // lz_search's own entry test
+                    l2[u] = ok[u] ? (uint32_t)slink[l1[u] - org] : 0u;
+                    cw[u] = ok[u] ? load_u32(sdata, l1[u] - org) : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t p = ts + q[u], limit = p > kMaxDist ? p - kMaxDist : 0u;
+                    const bool push = ok[u] && (l2[u] > limit || ((cw[u] ^ scan[u]) & 0xffffffu) == 0u);
+                    const uint64_t m = __ballot(push);
+                    if (push) wl[nl + (uint32_t)__popcll(m & lanes_below())] = (uint16_t)q[u];
+                    nl += (uint32_t)__popcll(m);
+                }
+            }
+            drain();
         }
         __syncthreads();
         for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads)
