@@ -40,8 +40,8 @@ def parse_args():
     ap.add_argument("--workload", default="random", choices=["random", "text"])
     ap.add_argument("--files", type=int, default=10000)
     ap.add_argument("--file-bytes", type=int, default=262144)
-    ap.add_argument("--max-batch", type=int, default=8192)
-    ap.add_argument("--cpu-sample-files", type=int, default=600)
+    ap.add_argument("--max-batch", type=int, default=51200)   # whole config-2 batch in one launch per kernel: ~48 GB of workspace, sized for 288 GB of HBM
+    ap.add_argument("--cpu-sample-files", type=int, default=2400)   # ~12-17 s of reference CPU work
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks share cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
