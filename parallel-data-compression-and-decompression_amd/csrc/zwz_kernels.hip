@@ -76,15 +76,21 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     for (uint32_t i = tid; i < (65536u + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
 
     // ---- feeder
-    auto hash_block = [&](uint32_t k) {            // hashes of positions [2048 k, 2048 k + 2048): 32 per lane
+    // the feeder keeps the next block's input in registers, loaded one hand-over ahead: a block's ~2 us of HBM
+    // latency is then hidden behind the previous block's work (issued and consumed in the same hand-over it was the
+    // critical path of the whole kernel: 5 k cycles per block against the inserter's 2.5 k)
+    uint4 in_a = make_uint4(0, 0, 0, 0), in_b = in_a; uint32_t in_c = 0;
+    auto load_block = [&](uint32_t k) {            // input bytes [2048 k + 32 lane, + 36) -> in_a, in_b, in_c
         const uint32_t o = k * kLinksBlock + lane * 32u;
-        uint32_t w[9];
         const uint4* g = reinterpret_cast<const uint4*>(data + o);
-        uint4 a = make_uint4(0, 0, 0, 0), b = a; uint32_t c = 0;
-        if (o + 16u <= Lr) a = g[0];
-        if (o + 32u <= Lr) b = g[1];
-        if (o + 36u <= Lr) c = reinterpret_cast<const uint32_t*>(data + o)[8];
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c;
+        in_a = make_uint4(0, 0, 0, 0); in_b = in_a; in_c = 0;
+        if (o + 16u <= Lr) in_a = g[0];
+        if (o + 32u <= Lr) in_b = g[1];
+        if (o + 36u <= Lr) in_c = reinterpret_cast<const uint32_t*>(data + o)[8];
+    };
+    auto hash_block = [&](uint32_t k) {            // hashes of positions [2048 k, 2048 k + 2048) from the loaded input: 32 per lane
+        const uint32_t o = k * kLinksBlock + lane * 32u;
+        const uint32_t w[9] = {in_a.x, in_a.y, in_a.z, in_a.w, in_b.x, in_b.y, in_b.z, in_b.w, in_c};
         const uint32_t n_ok = L >= o + kMinMatch ? min(32u, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
         uint32_t packed[16];
 #pragma unroll
@@ -120,90 +126,239 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     };
 
     // ---- inserter
-    struct Step { uint32_t p16, hsh, prev, rb, patch, slot; };
-    constexpr uint32_t kNoPatch = 0xffffffffu;
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
-    const uint32_t head_a = (uint32_t)(uintptr_t)(lds_ptr)reinterpret_cast<uint8_t*>(head);   // LDS byte addresses
+    const uint32_t head_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(head));   // LDS byte addresses
     const uint32_t hbuf_a = head_a + 2u * (32768u + 8u);
-    auto read_hash = [&](uint32_t addr) -> uint32_t {
-        uint32_t h;
-        asm volatile("ds_read_u16 %0, %1" : "=v"(h) : "v"(addr) : "memory");
-        return h;
+    struct Step { uint32_t p16, prev, rb; };           // position, head read, read-back of one 64-position step
+    auto lds_u16 = [&](uint32_t addr) -> uint32_t {    // complete on return
+        uint32_t v;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        return v;
     };
-    auto issue = [&](Step& S, uint32_t p16, uint32_t h, uint32_t slot) {
-        S.p16 = p16; S.hsh = h; S.patch = kNoPatch; S.slot = slot;
+    auto issue_and_wait = [&](Step& S, uint32_t h) {   // the slow path's version of a step's three operations
         const uint32_t bucket = head_a + 2u * h;
-        // colliding lanes: one store wins, fixed at retire; the read-back sees the other lanes' stores
-        asm volatile("ds_read_u16 %0, %2\n\tds_write_b16 %2, %3\n\tds_read_u16 %1, %2"
-                     : "=&v"(S.prev), "=&v"(S.rb) : "v"(bucket), "v"(p16) : "memory");
+        asm volatile("ds_read_u16 %0, %2\n\tds_write_b16 %2, %3\n\tds_read_u16 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(S.prev), "=&v"(S.rb) : "v"(bucket), "v"(S.p16) : "memory");
     };
-    auto retire = [&](Step& S, uint32_t& n_hsh, uint32_t& n_patch) {   // n_* = the step issued after S
-        uint32_t prev = S.patch != kNoPatch ? S.patch : S.prev;
+    // Collision repair of a complete step S.  Up to two later steps (N1, then N2) have been issued behind it and are
+    // complete too; a step's hashes sit in its buffer slots until its links replace them.
+    // Lanes of S sharing a hash all read the old head and one arbitrary store won: every lane but the lowest of a
+    // group links to its next lower peer, and the bucket belongs to the newest peer -- unless a later step already
+    // stored a newer position there.  The first later step holding that hash read an arbitrary peer of S with its
+    // lowest such lane, which gets the newest peer instead (its other lanes, and whatever N2 read from N1's stores,
+    // are that step's own repair).
+    auto repair = [&](Step& S, uint32_t slot_s, bool has1, Step& N1, bool has2, Step& N2) {
         uint64_t dup = __builtin_amdgcn_uicmp(S.rb, S.p16, 33 /* ICMP_NE */);
+        if (dup == 0) return;
+        const uint32_t h_s = lds_u16(slot_s);
+        const uint32_t h_1 = has1 ? lds_u16(slot_s + 128u) : 0xffffffffu, h_2 = has2 ? lds_u16(slot_s + 256u) : 0xffffffffu;
+        const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(S.p16);
         while (dup) {  // wave-uniform: one iteration per hash value shared inside step S
             const uint32_t l = (uint32_t)__builtin_ctzll(dup);
-            const uint32_t hh = __builtin_amdgcn_readlane(S.hsh, l);
-            const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(S.p16) - __builtin_amdgcn_readfirstlane(lane);
-            const uint64_t peers = __builtin_amdgcn_uicmp(S.hsh, hh, 32 /* ICMP_EQ */);
+            const uint32_t hh = __builtin_amdgcn_readlane(h_s, l);
+            const uint64_t peers = __builtin_amdgcn_uicmp(h_s, hh, 32 /* ICMP_EQ */);
             const uint32_t top = 63u - (uint32_t)__builtin_clzll(peers), newest = p_lane0 + top;
-            if (S.hsh == hh) {
+            if (h_s == hh) {
                 const uint64_t lower = peers & lanes_below();
-                if (lower) prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
+                if (lower) S.prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
             }
-            const uint64_t after = __builtin_amdgcn_uicmp(n_hsh, hh, 32);
-            if (after == 0) { if (lane == top) head[hh] = (uint16_t)newest; }     // newest peer owns the bucket
-            else if (n_hsh == hh) n_patch = newest;                                // the next step's own repair overrides all but its lowest peer
+            const uint64_t a1 = __builtin_amdgcn_uicmp(h_1, hh, 32), a2 = __builtin_amdgcn_uicmp(h_2, hh, 32);
+            if (a1) { if (lane == (uint32_t)__builtin_ctzll(a1)) N1.prev = newest; }
+            else if (a2) { if (lane == (uint32_t)__builtin_ctzll(a2)) N2.prev = newest; }
+            else if (lane == top) head[hh] = (uint16_t)newest;                    // newest peer owns the bucket
             dup &= ~peers;
         }
-        asm volatile("ds_write_b16 %0, %1" :: "v"(S.slot), "v"(prev) : "memory");  // the link replaces the hash in the buffer
     };
+    auto write_link = [&](uint32_t slot, uint32_t prev) {   // the link replaces the hash in the buffer
+        asm volatile("ds_write_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(slot), "v"(prev) : "memory");
+    };
+    uint32_t slow_exits = 0;                          // collisions of the last block that needed the general repair
     auto insert_block = [&](uint32_t k) {
+        slow_exits = 0;
         const uint32_t first = k * kLinksBlock;
-        const uint32_t n_steps = (min(L, first + kLinksBlock) - first + 63u) / 64u;      // >= 1
-        uint32_t slot = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);                   // this lane's entry of the step to issue
-        uint32_t p16 = first + lane;
-        Step A, B;
-        uint32_t none_h = 0xffffffffu, none_p = kNoPatch;
-        uint32_t hx = read_hash(slot), hn = read_hash(slot + 128u);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hx), "+v"(hn) :: "memory");
-        issue(A, p16, hx, slot);
-        hx = hn;
-        uint32_t s = 0;
-        // A = step s in flight; hx = hashes of step s+1 (read, complete)
-        while (s + 2 < n_steps) {
-            hn = read_hash(slot + 256u);                                                  // step s+2
-            issue(B, p16 + 64u, hx, slot + 128u);
-            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A.prev), "+v"(A.rb), "+v"(hn) :: "memory");
-            retire(A, B.hsh, B.patch);
-            hx = hn;
-            hn = read_hash(slot + 384u);                                                  // step s+3 (may lie past the block: unused then)
-            issue(A, p16 + 128u, hx, slot + 256u);
-            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B.prev), "+v"(B.rb), "+v"(hn) :: "memory");
-            retire(B, A.hsh, A.patch);
-            hx = hn;
-            s += 2; p16 += 128u; slot += 256u;
+        const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);      // >= 1
+        uint32_t base = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);                    // this lane's buffer entry of step s
+        Step P0, P1, P2;
+        uint32_t s = 0;                                                                   // P0 = step s, P1 = step s + 1: issued, complete
+        P0.p16 = first + lane; P1.p16 = P0.p16 + 64u; P2.p16 = P0.p16 + 128u;
+        uint32_t h0 = 0, h1 = 0, h2 = 0;
+        issue_and_wait(P0, lds_u16(base));
+        if (n_steps > 1) issue_and_wait(P1, lds_u16(base + 128u));
+        for (;;) {
+            uint32_t left = __builtin_amdgcn_readfirstlane(n_steps > s + 2u ? n_steps - 2u - s : 0u);   // steps not issued yet
+            if (left < 3u) break;
+            uint32_t hs0 = lds_u16(base), hs1 = lds_u16(base + 128u), hs2 = 0;            // hashes of the steps in P0, P1 (still in their slots)
+            h2 = lds_u16(base + 256u); h0 = lds_u16(base + 384u);                         // ... and of the next two steps to issue
+            // Steady state, three steps a trip (three register sets take turns), entered with nothing in flight.  Per
+            // step t: the hashes of step t+2 are read, the three operations of step t are issued, and only then is the
+            // read-back of step t-2 looked at -- two steps of other work cover every LDS round trip.  LDS returns in
+            // order, so both "the hashes of t are back" and "step t-2 is back" are lgkmcnt(10): that many younger
+            // operations sit in the queue behind them.
+            // A collision inside the retiring step (two lanes, one hash: 6 % of the steps on random bytes) is repaired
+            // in place by the lane whose store lost -- its read-back names the winner: if the winner is the higher
+            // lane the bucket is right and only the winner's link (already written to its buffer slot) must become
+            // the loser's position; if the winner is the lower lane the loser links to it and re-stores itself in the
+            // bucket.  Anything else (several losers, a later step already holding that hash) goes out to C++.
+            uint32_t code, bk, t32, hh; uint64_t dm, sv;
+            // issue step t (hashes HC, read two steps ago), read the hashes of step t+2, retire step t-2
+#define ZWZ_LINK_STEP(HN, HN_OFF, HC, HSC, PC, RC, PPOS, PR, RR, RPOS, ROFF, FIX, BACK)              \
+                "ds_read_u16 %[" HN "], %[base] offset:" HN_OFF "\n\t"                                 \
+                "s_waitcnt lgkmcnt(10)\n\t"                                                          \
+                "v_lshl_add_u32 %[bk], %[" HC "], 1, %[head]\n\t"                                    \
+                "v_mov_b32 %[" HSC "], %[" HC "]\n\t"                                                \
+                "ds_read_u16 %[" PC "], %[bk]\n\t"                                                   \
+                "ds_write_b16 %[bk], %[" PPOS "]\n\t"                                                \
+                "ds_read_u16 %[" RC "], %[bk]\n\t"                                                   \
+                "s_waitcnt lgkmcnt(10)\n\t"                                                          \
+                "v_cmp_ne_u32 vcc, %[" RR "], %[" RPOS "]\n\t"                                       \
+                "s_cbranch_vccnz " FIX "f\n\t"                                                       \
+                "ds_write_b16 %[base], %[" PR "] offset:" ROFF "\n\t"                                \
+                BACK ":\n\t"                                                                         \
+                "v_add_u32 %[" RPOS "], 0xc0, %[" RPOS "]\n\t"
+            // out of line: the loser lane's repair (then back into the loop), or out to C++
+#define ZWZ_LINK_FIX(FIX, BACK, PR, RR, RPOS, ROFF, HSR, HS1, HS2, EXIT)                             \
+                FIX ":\n\t"                                                                          \
+                "s_mov_b64 %[dm], vcc\n\t"                                                           \
+                "s_bcnt1_i32_b64 %[t32], vcc\n\t"                                                    \
+                "s_cmp_eq_u32 %[t32], 1\n\t"                                                         \
+                "s_cbranch_scc0 " EXIT "f\n\t"                                                       \
+                "s_ff1_i32_b64 %[t32], vcc\n\t"                                                      \
+                "v_readlane_b32 %[hh], %[" HSR "], %[t32]\n\t"                                       \
+                "v_cmp_eq_u32 vcc, %[hh], %[" HS1 "]\n\t"                                            \
+                "s_cbranch_vccnz " EXIT "f\n\t"                                                      \
+                "v_cmp_eq_u32 vcc, %[hh], %[" HS2 "]\n\t"                                            \
+                "s_cbranch_vccnz " EXIT "f\n\t"                                                      \
+                "s_and_saveexec_b64 %[sv], %[dm]\n\t"                                                \
+                "v_cmp_gt_u32 vcc, %[" RR "], %[" RPOS "]\n\t"                                       \
+                "v_cndmask_b32 %[" PR "], %[" RR "], %[" PR "], vcc\n\t"                             \
+                "v_sub_u32 %[bk], %[" RR "], %[" RPOS "]\n\t"                                        \
+                "v_lshl_add_u32 %[bk], %[bk], 1, %[base]\n\t"                                        \
+                "s_mov_b64 exec, %[sv]\n\t"                                                          \
+                "ds_write_b16 %[base], %[" PR "] offset:" ROFF "\n\t"                                \
+                "s_and_b64 exec, %[dm], vcc\n\t"                                                     \
+                "ds_write_b16 %[bk], %[" RPOS "] offset:" ROFF "\n\t"                                \
+                "s_andn2_b64 exec, %[dm], vcc\n\t"                                                   \
+                "v_lshl_add_u32 %[bk], %[" HSR "], 1, %[head]\n\t"                                   \
+                "ds_write_b16 %[bk], %[" RPOS "]\n\t"                                                \
+                "s_mov_b64 exec, %[sv]\n\t"                                                          \
+                "s_branch " BACK "b\n\t"
+            asm volatile(
+                "1:\n\t"
+                ZWZ_LINK_STEP("h1", "512", "h2", "hs2", "prev2", "rb2", "p2", "prev0", "rb0", "p0", "0", "20", "30")      /* issue s+2, retire s */
+                ZWZ_LINK_STEP("h2", "640", "h0", "hs0", "prev0", "rb0", "p0", "prev1", "rb1", "p1", "128", "21", "31")    /* issue s+3, retire s+1 */
+                ZWZ_LINK_STEP("h0", "768", "h1", "hs1", "prev1", "rb1", "p1", "prev2", "rb2", "p2", "256", "22", "32")    /* issue s+4, retire s+2 */
+                "v_add_u32 %[base], 0x180, %[base]\n\t"
+                "s_sub_u32 %[left], %[left], 3\n\t"
+                "s_cmp_gt_u32 %[left], 2\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[code], 3\n\t"
+                "s_branch 9f\n\t"
+                ZWZ_LINK_FIX("20", "30", "prev0", "rb0", "p0", "0", "hs0", "hs1", "hs2", "5")
+                ZWZ_LINK_FIX("21", "31", "prev1", "rb1", "p1", "128", "hs1", "hs2", "hs0", "6")
+                ZWZ_LINK_FIX("22", "32", "prev2", "rb2", "p2", "256", "hs2", "hs0", "hs1", "7")
+                "5:\n\t"
+                "s_mov_b32 %[code], 0\n\t"
+                "s_branch 9f\n\t"
+                "6:\n\t"
+                "s_mov_b32 %[code], 1\n\t"
+                "s_branch 9f\n\t"
+                "7:\n\t"
+                "s_mov_b32 %[code], 2\n\t"
+                "9:\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [hs0] "+v"(hs0), [hs1] "+v"(hs1), [hs2] "+v"(hs2),
+                  [prev0] "+v"(P0.prev), [rb0] "+v"(P0.rb), [prev1] "+v"(P1.prev), [rb1] "+v"(P1.rb),
+                  [prev2] "+v"(P2.prev), [rb2] "+v"(P2.rb), [p0] "+v"(P0.p16), [p1] "+v"(P1.p16), [p2] "+v"(P2.p16), [base] "+v"(base),
+                  [left] "+s"(left), [code] "=&s"(code), [bk] "=&v"(bk), [t32] "=&s"(t32), [hh] "=&s"(hh), [dm] "=&s"(dm), [sv] "=&s"(sv)
+                : [head] "s"(head_a)
+                : "vcc", "scc", "memory");
+#undef ZWZ_LINK_FIX
+#undef ZWZ_LINK_STEP
+            s = n_steps - 2u - left;                   // step held by P0 when the interrupted (or last) trip began
+            if (code == 3u) break;                     // P0 = step s, P1 = step s+1 complete
+            slow_exits++;
+            if (code == 0u) {
+                // collision in step s (P0); P1 = s+1 and P2 = s+2 are issued; h0 = hashes of s + 3
+                repair(P0, base, true, P1, true, P2);
+                write_link(base, P0.prev);
+                P0 = P1; P1 = P2; P2.p16 = P1.p16 + 64u;
+                s += 1u; base += 128u;
+            } else if (code == 1u) {
+                // collision in step s+1 (P1); link of s written; P2 = s+2 and P0 = s+3 are issued; h1 = hashes of s + 4
+                repair(P1, base + 128u, true, P2, true, P0);
+                write_link(base + 128u, P1.prev);
+                const Step t = P0; P0 = P2; P1 = t; P2.p16 = P1.p16 + 64u;
+                s += 2u; base += 256u;
+            } else {
+                // collision in step s+2 (P2); links of s, s+1 written; P0 = s+3 and P1 = s+4 are issued; h2 = hashes of s + 5
+                repair(P2, base + 256u, true, P0, true, P1);
+                write_link(base + 256u, P2.prev);
+                P2.p16 = P1.p16 + 64u;
+                s += 3u; base += 384u;
+            }
         }
-        if (s + 1 < n_steps) {
-            issue(B, p16 + 64u, hx, slot + 128u);
-            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A.prev), "+v"(A.rb) :: "memory");
-            retire(A, B.hsh, B.patch);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(B.prev), "+v"(B.rb) :: "memory");
-            retire(B, none_h, none_p);
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A.prev), "+v"(A.rb) :: "memory");
-            retire(A, none_h, none_p);
+        // fewer than three steps left to issue: one at a time.  P0 = step s and (if it exists) P1 = step s+1 are complete.
+        while (s + 1u < n_steps) {
+            repair(P0, base, true, P1, false, P1);
+            write_link(base, P0.prev);
+            P0 = P1; s += 1u; base += 128u;
+            if (s + 1u < n_steps) { P1.p16 = P0.p16 + 64u; issue_and_wait(P1, lds_u16(base + 128u)); }
+        }
+        repair(P0, base, false, P0, false, P0);
+        write_link(base, P0.prev);
+    };
+
+    // Collision-dense data (text: most steps hold several repeated trigrams): every step would leave the pipelined
+    // loop, so such blocks run one step at a time -- nothing is ever issued behind the step under repair.
+    auto insert_block_dense = [&](uint32_t k) {
+        const uint32_t first = k * kLinksBlock;
+        const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);
+        uint32_t base = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);
+        Step P; P.p16 = first + lane;
+        uint32_t h = lds_u16(base), collided = 0;
+        for (uint32_t st = 0; st < n_steps; st++) {
+            uint32_t hn;
+            const uint32_t bucket = head_a + 2u * h;
+            asm volatile("ds_read_u16 %0, %3 offset:128\n\tds_read_u16 %1, %4\n\tds_write_b16 %4, %5\n\tds_read_u16 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(hn), "=&v"(P.prev), "=&v"(P.rb) : "v"(base), "v"(bucket), "v"(P.p16) : "memory");
+            uint64_t dup = __builtin_amdgcn_uicmp(P.rb, P.p16, 33 /* ICMP_NE */);
+            if (dup) {
+                collided++;
+                const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(P.p16);
+                while (dup) {  // wave-uniform: one iteration per hash value shared inside the step
+                    const uint32_t hh = __builtin_amdgcn_readlane(h, (uint32_t)__builtin_ctzll(dup));
+                    const uint64_t peers = __builtin_amdgcn_uicmp(h, hh, 32 /* ICMP_EQ */);
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(peers);
+                    if (h == hh) {
+                        const uint64_t lower = peers & lanes_below();
+                        if (lower) P.prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
+                        if (lane == top) head[hh] = (uint16_t)P.p16;              // newest peer owns the bucket
+                    }
+                    dup &= ~peers;
+                }
+            }
+            asm volatile("ds_write_b16 %0, %1" :: "v"(base), "v"(P.prev) : "memory");
+            h = hn; P.p16 += 64u; base += 128u;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slow_exits = collided;                            // stay dense while most steps collide
     };
 
     __syncthreads();
-    if (wave == 1) hash_block(0);
+    if (wave == 1) {
+        load_block(0);
+        hash_block(0);
+        if (n_blocks > 1) load_block(1);
+    }
     __syncthreads();
     for (uint32_t k = 0; k < n_blocks; k++) {
-        if (wave == 0) insert_block(k);
+        if (wave == 0) { if (slow_exits >= 6u) insert_block_dense(k); else insert_block(k); }
         else {
             if (k >= 1) flush_block(k - 1);
-            if (k + 1 < n_blocks) hash_block(k + 1);
+            if (k + 1 < n_blocks) {
+                hash_block(k + 1);
+                if (k + 2 < n_blocks) load_block(k + 2);
+            }
         }
         __syncthreads();
     }
