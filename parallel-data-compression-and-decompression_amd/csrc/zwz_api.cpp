@@ -244,6 +244,7 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.m32 = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
+    a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
     a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));

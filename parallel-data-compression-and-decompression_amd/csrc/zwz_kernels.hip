@@ -59,14 +59,15 @@ constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over be
 constexpr uint32_t kLinksNoHash = 32768;           // "hash" of a position without a trigram
 
 __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
-                                                                 const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links) {
+                                                                 const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
+                                                                 uint32_t* __restrict__ link_stat) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
     extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries + the dummy slot
     uint16_t* hbuf = head + 32768 + 8;                                       // 2 x kLinksBlock: hashes in, links out
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t L = in_len[chunk];
-    if (L == 0) return;
+    if (L == 0) { if (tid == 0) link_stat[chunk] = 0; return; }
     const uint8_t* data = in + in_off[chunk];                                // 16-byte aligned (API contract)
     uint16_t* lk = links + (size_t)chunk * kLinkStride;
     const uint32_t Lr = (L + 15u) & ~15u;                                    // the slot is readable this far
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) dst[j] = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
     };
+    uint32_t linked = 0;                               // feeder: positions of this lane with a chain predecessor
     auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
         const uint32_t o = k * kLinksBlock + lane * 32u;
         const uint4* src = reinterpret_cast<const uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 v = make_uint4(e[0], e[1], e[2], e[3]);
             }
             dst[j] = v;
+            linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0)
+                    + (uint32_t)((v.z & 0xffffu) != 0) + (uint32_t)((v.z >> 16) != 0) + (uint32_t)((v.w & 0xffffu) != 0) + (uint32_t)((v.w >> 16) != 0);
         }
     };
 
@@ -362,7 +366,11 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         }
         __syncthreads();
     }
-    if (wave == 1) flush_block(n_blocks - 1);
+    if (wave == 1) {
+        flush_block(n_blocks - 1);
+        for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
+        if (lane == 0) link_stat[chunk] = linked;       // lz_match picks its work order by it
+    }
 }
 
 // Workgroup copy of n 16-byte vectors global -> LDS with eight loads in flight per thread.
@@ -492,7 +500,7 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128,
-                                                                 uint16_t* __restrict__ perms) {
+                                                                 uint16_t* __restrict__ perms, const uint32_t* __restrict__ link_stat) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
@@ -528,6 +536,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         if (llo + tid < lhi) pl0 = gl4[llo + tid];                                                 \
         if (llo + tid + kMatchThreads < lhi) pl1 = gl4[llo + tid + kMatchThreads];                 \
     }
+    // chain-heavy data (four of five positions have a chain predecessor: text) takes the sorted work order, sparse
+    // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
+    const bool sorted_order = link_stat[chunk] * 5u >= L * 4u;      // workgroup-uniform
     uint32_t org = 0;
     ZWZ_PREFETCH(0u)
     for (uint32_t t = 0; t < ntiles; t++) {
@@ -546,8 +557,8 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         // lengths run from 1 to 128 among neighbouring positions (21-29% VALU lane utilisation on
         // text).  Positions with a similar distance to their second predecessor have similar chain
         // lengths, so the tile is counting-sorted by an 8-bucket key of that distance and waves take 64
-        // positions of one bucket at a time (~0.58 utilisation, half the trips).  Tiles that look
-        // incompressible (few positions with two predecessors in range) keep the natural order.
+        // positions of one bucket at a time (~0.58 utilisation, half the trips).  Chunks with sparse
+        // chains (lz_links' count, above) take the screening pass instead.
         const uint32_t npos = te - ts;
         const uint32_t wave = tid >> 6, lane = lane_id();
         auto key_of = [&](uint32_t p) -> uint32_t {
@@ -560,12 +571,6 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             return (lg > 13u ? 13u : lg) >> 1;
         };
         for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of this tile (32-bit words)
-        const uint32_t sample = (uint32_t)__popcll(__ballot(key_of(ts + tid) < 7u));
-        if (lane == 0) s_cnt[wave] = (uint16_t)sample;
-        __syncthreads();
-        uint32_t chained = 0;
-        for (uint32_t i = 0; i < kMatchThreads / 64; i++) chained += s_cnt[i];
-        const bool sorted_order = chained * 2u >= min(npos, kMatchThreads);      // wave-uniform, workgroup-uniform
         __syncthreads();
         if (sorted_order) {
             // counts[bucket][trip][wave] -> exclusive scan -> destination of every position
@@ -1698,10 +1703,10 @@ hipError_t configure_kernels() {
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links);
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
-                       a.links, a.entries, a.has128, a.perm);
+                       a.links, a.entries, a.has128, a.perm, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
