@@ -85,6 +85,34 @@ def test_deflate_fuzz_many_small(codec, oracle):
     assert not bad, bad[:10]
 
 
+def test_deflate_fuzz_large_and_mixed(codec, oracle):
+    """Mid-size and full-size chunks of every kind, plus chunks stitched from segments of different kinds: the
+    kernels switch work order / collision handling by what a chunk (or a 2048-position block of it) looks like."""
+    rs = corpus.splitmix64(424242, 4 * 200)
+    kinds = [k for k in corpus.KINDS if k != "lz"]
+    chunks = []
+    for i in range(120):
+        kind = kinds[int(rs[4 * i] % len(kinds))]
+        n = 3000 + int(rs[4 * i + 1] % 62536)
+        chunks.append(corpus.make(kind, 30000 + i, n))
+    for i in range(120, 170):
+        parts, total = [], 0
+        for j in range(2 + int(rs[4 * i] % 3)):
+            kind = kinds[int(rs[4 * i + 1 + (j % 3)] >> (8 * j)) % len(kinds)]
+            n = 500 + int((rs[4 * i + 2] >> (13 * j)) % 24000)
+            n = min(n, 65535 - total)
+            if n <= 0:
+                break
+            parts.append(corpus.make(kind, 31000 + 7 * i + j, n)); total += n
+        chunks.append(b"".join(parts))
+    got = codec.deflate_chunks(chunks)
+    bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
+    assert not bad, bad[:10]
+    back, _ = codec.inflate_chunks(got)
+    wrong = [i for i, (g, b) in enumerate(zip(got, back)) if b != oracle.inflate(g, 70000)[0]]
+    assert not wrong, wrong[:10]
+
+
 def test_inflate_matches_oracle(codec, oracle):
     import zlib
     payloads, want = [], []
