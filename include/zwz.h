@@ -19,6 +19,8 @@
  *   zwz_sort_files_by_size sort_files_by_size(path), process.hpp:37 / file_sort.cpp:24-43
  *   zwz_count_non_empty_lines  count_non_empty_lines(file), process.hpp:38 / file_tools.cpp:6-23
  *   zwz_md5_of_file        md5_of_file(path), process.hpp:41 / verification.cpp:6-30
+ *   zwz_md5_files_dev      the same digest for many files at once, from their chunks in device memory
+ *                          (the call sites compression.cpp:98 and decompression.cpp:136 batched)
  *
  * Conventions: plain pointers and sizes, no exceptions across the boundary, 0 = success and
  * negative zwz_status codes otherwise, caller owns every buffer.  A context binds one GPU, one
@@ -99,6 +101,13 @@ int zwz_inflate_batch(zwz_ctx *ctx, const uint8_t *in, const uint64_t *in_off, c
 #define ZWZ_NUM_STAGES 7
 int zwz_ctx_set_profiling(zwz_ctx *ctx, int on);
 int zwz_ctx_stage_ms(zwz_ctx *ctx, float *ms, int reset);
+
+/* MD5 (RFC 1321) of n_files files whose bytes already sit in device chunk slots: file i is the concatenation
+ * of slots d_files[2i] .. d_files[2i] + d_files[2i+1] - 1 (slot k = d_in_len[k] bytes at d_in + d_in_off[k]).
+ * d_digests receives 16 bytes per file (4-byte aligned).  Asynchronous on the context's stream.  One lane per
+ * file: meant for many small and medium files; hash very large files on the host (zwz_md5_of_file). */
+int zwz_md5_files_dev(zwz_ctx *ctx, const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                      const uint32_t *d_files, uint32_t n_files, uint8_t *d_digests);
 
 /* ---- directory level (the reference's per-rank pipeline) ------------------------------------ */
 int zwz_sort_files_by_size(const char *src_dir, char *record_path_out, size_t cap);

@@ -60,6 +60,7 @@ def lib():
         L.zwz_sort_files_by_size.argtypes = [c.c_char_p, c.c_char_p, c.c_size_t]
         L.zwz_count_non_empty_lines.argtypes = [c.c_char_p]
         L.zwz_md5_of_file.argtypes = [c.c_char_p, c.c_char_p]
+        L.zwz_md5_files_dev.argtypes = [vp, vp, vp, vp, vp, u32, vp]
         L.zwz_compress_dir.argtypes = [vp, c.c_char_p, c.c_char_p, c.c_char_p, c.c_int, c.c_int]
         L.zwz_decompress_dir.argtypes = [vp, c.c_char_p, c.c_char_p, c.POINTER(c.c_int)]
         _lib = L
@@ -149,6 +150,13 @@ class Codec:
         _check(lib().zwz_inflate_batch(self._h, src.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, out.ctypes.data,
                                        olen.ctypes.data, st.ctypes.data), "zwz_inflate_batch")
         return ([out[i * CHUNK_SIZE:i * CHUNK_SIZE + int(olen[i])].tobytes() for i in range(n)], [int(s) for s in st[:n]])
+
+    def md5_files_dev(self, d_in, d_off, d_len, d_files, d_digests):
+        """MD5 of whole files from their chunk slots in device memory: d_files = int32 pairs (first slot, slots),
+        d_digests = 16 bytes per file (md5_of_file(), verification.cpp:6-30, batched).  Asynchronous."""
+        n_files = d_files.numel() // 2
+        _check(lib().zwz_md5_files_dev(self._h, d_in.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_files.data_ptr(), n_files,
+                                       d_digests.data_ptr()), "zwz_md5_files_dev")
 
     # ---- device-resident torch tensors (asynchronous on self.stream) ---------------------------
     def deflate_dev(self, d_in, d_off, d_len, d_out, d_out_len, out_stride=DEV_STRIDE):

@@ -143,6 +143,15 @@ int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
     return ZWZ_OK;
 }
 
+int zwz_md5_files_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, const uint32_t* d_files,
+                      uint32_t n_files, uint8_t* d_digests) {
+    if (!c || (n_files && (!d_in || !d_in_off || !d_in_len || !d_files || !d_digests))) return ZWZ_E_INVALID;
+    if ((uintptr_t)d_digests & 3u) return ZWZ_E_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_md5_files(d_in, d_in_off, d_in_len, d_files, n_files, reinterpret_cast<uint32_t*>(d_digests), c->stream));
+    return ZWZ_OK;
+}
+
 int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                           uint8_t* d_out, uint64_t out_stride, uint32_t* d_out_len, uint32_t* d_status) {
     if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len || !d_status))) return ZWZ_E_INVALID;

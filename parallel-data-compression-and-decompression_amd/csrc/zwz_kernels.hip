@@ -21,6 +21,7 @@
 #include "huff_core.h"
 #include "inflate_core.h"
 #include "lz_core.h"
+#include "zwz_md5.h"
 #include "zwz_kernels.h"
 
 namespace zwz {
@@ -1720,6 +1721,81 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
                        a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len);
     if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// md5_files: RFC 1321 digest of whole files whose bytes sit in consecutive chunk slots (SURVEY.md §8 f1;
+// md5_of_file(), verification.cpp:6-30).  MD5 is a chain over a file's 64-byte blocks, so the parallel axis
+// is the file: one lane per file, the sixteen message words and the state in registers, the 64 steps fully
+// unrolled (shared with the host class through ZWZ_MD5_STEPS).  A file's bytes are not contiguous -- slots
+// hold 65 535 bytes on a 65 536 stride -- so words are fetched through a small cursor that steps from slot
+// to slot and assembles the one word per chunk that straddles a boundary byte by byte.
+struct Md5Cursor {
+    const uint8_t* in; const uint64_t* off; const uint32_t* len;
+    uint32_t slot; const uint8_t* ptr; uint32_t rem;
+    __device__ __forceinline__ void open(uint32_t s) { slot = s; ptr = in + off[s]; rem = len[s]; }
+    __device__ __forceinline__ uint32_t byte() {           // caller guarantees the file has bytes left
+        while (rem == 0) open(slot + 1);
+        rem--;
+        return *ptr++;
+    }
+    __device__ __forceinline__ uint32_t word() {
+        if (rem >= 4u) { uint32_t v; __builtin_memcpy(&v, ptr, 4); ptr += 4; rem -= 4; return v; }
+        uint32_t v = byte();
+        v |= byte() << 8; v |= byte() << 16; v |= byte() << 24;
+        return v;
+    }
+};
+
+__global__ __launch_bounds__(64) void md5_files_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                       const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ files,
+                                                       uint32_t n_files, uint32_t* __restrict__ digests) {
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f >= n_files) return;
+    const uint32_t slot0 = files[2 * f], nslots = files[2 * f + 1];
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nslots; i++) total += in_len[slot0 + i];
+    auto rol = [](uint32_t x, int sh) { return __builtin_rotateleft32(x, (uint32_t)sh); };
+    uint32_t h0 = 0x67452301u, h1 = 0xefcdab89u, h2 = 0x98badcfeu, h3 = 0x10325476u;
+    uint32_t w[16];
+#define ZWZ_MD5_BLOCK { uint32_t a = h0, b = h1, c = h2, d = h3; ZWZ_MD5_STEPS h0 += a; h1 += b; h2 += c; h3 += d; }
+    Md5Cursor cur{in, in_off, in_len, 0, nullptr, 0};
+    if (nslots) cur.open(slot0);
+    for (uint64_t blk = 0; blk < total / 64u; blk++) {
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) w[j] = cur.word();
+        ZWZ_MD5_BLOCK
+    }
+    // padding: the rest of the message, 0x80, zeros, the bit length in the last two words of a block
+    const uint32_t r = (uint32_t)(total & 63u);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t pos = 4u * j + k;
+            const uint32_t bt = pos < r ? cur.byte() : (pos == r ? 0x80u : 0u);
+            v |= bt << (8u * k);
+        }
+        w[j] = v;
+    }
+    const uint64_t bits = total * 8u;
+    if (r >= 56u) {
+        ZWZ_MD5_BLOCK
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) w[j] = 0;
+    }
+    w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32);
+    ZWZ_MD5_BLOCK
+#undef ZWZ_MD5_BLOCK
+    digests[4 * f] = h0; digests[4 * f + 1] = h1; digests[4 * f + 2] = h2; digests[4 * f + 3] = h3;   // little-endian: the 16 digest bytes
+}
+
+hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,
+                            uint32_t* digests, hipStream_t s) {
+    if (n_files == 0) return hipSuccess;
+    hipLaunchKernelGGL(md5_files_kernel, dim3((n_files + 63u) / 64u), dim3(64), 0, s, in, in_off, in_len, files, n_files, digests);
     return hipGetLastError();
 }
 

@@ -4,6 +4,30 @@
 #include <cstdint>
 #include <cstring>
 
+// The 64 steps of one block on the working variables a, b, c, d and the sixteen message words w[0..15];
+// rol must be in scope.  Shared by the host class below and the device kernel (zwz_kernels.hip: md5_files).
+#define ZWZ_MD5_R1(a, b, c, d, k, s, t) a = b + rol(a + ((b & c) | (~b & d)) + w[k] + t, s)
+#define ZWZ_MD5_R2(a, b, c, d, k, s, t) a = b + rol(a + ((b & d) | (c & ~d)) + w[k] + t, s)
+#define ZWZ_MD5_R3(a, b, c, d, k, s, t) a = b + rol(a + (b ^ c ^ d) + w[k] + t, s)
+#define ZWZ_MD5_R4(a, b, c, d, k, s, t) a = b + rol(a + (c ^ (b | ~d)) + w[k] + t, s)
+#define ZWZ_MD5_STEPS \
+    ZWZ_MD5_R1(a,b,c,d,0,7,0xd76aa478u); ZWZ_MD5_R1(d,a,b,c,1,12,0xe8c7b756u); ZWZ_MD5_R1(c,d,a,b,2,17,0x242070dbu); ZWZ_MD5_R1(b,c,d,a,3,22,0xc1bdceeeu); \
+    ZWZ_MD5_R1(a,b,c,d,4,7,0xf57c0fafu); ZWZ_MD5_R1(d,a,b,c,5,12,0x4787c62au); ZWZ_MD5_R1(c,d,a,b,6,17,0xa8304613u); ZWZ_MD5_R1(b,c,d,a,7,22,0xfd469501u); \
+    ZWZ_MD5_R1(a,b,c,d,8,7,0x698098d8u); ZWZ_MD5_R1(d,a,b,c,9,12,0x8b44f7afu); ZWZ_MD5_R1(c,d,a,b,10,17,0xffff5bb1u); ZWZ_MD5_R1(b,c,d,a,11,22,0x895cd7beu); \
+    ZWZ_MD5_R1(a,b,c,d,12,7,0x6b901122u); ZWZ_MD5_R1(d,a,b,c,13,12,0xfd987193u); ZWZ_MD5_R1(c,d,a,b,14,17,0xa679438eu); ZWZ_MD5_R1(b,c,d,a,15,22,0x49b40821u); \
+    ZWZ_MD5_R2(a,b,c,d,1,5,0xf61e2562u); ZWZ_MD5_R2(d,a,b,c,6,9,0xc040b340u); ZWZ_MD5_R2(c,d,a,b,11,14,0x265e5a51u); ZWZ_MD5_R2(b,c,d,a,0,20,0xe9b6c7aau); \
+    ZWZ_MD5_R2(a,b,c,d,5,5,0xd62f105du); ZWZ_MD5_R2(d,a,b,c,10,9,0x02441453u); ZWZ_MD5_R2(c,d,a,b,15,14,0xd8a1e681u); ZWZ_MD5_R2(b,c,d,a,4,20,0xe7d3fbc8u); \
+    ZWZ_MD5_R2(a,b,c,d,9,5,0x21e1cde6u); ZWZ_MD5_R2(d,a,b,c,14,9,0xc33707d6u); ZWZ_MD5_R2(c,d,a,b,3,14,0xf4d50d87u); ZWZ_MD5_R2(b,c,d,a,8,20,0x455a14edu); \
+    ZWZ_MD5_R2(a,b,c,d,13,5,0xa9e3e905u); ZWZ_MD5_R2(d,a,b,c,2,9,0xfcefa3f8u); ZWZ_MD5_R2(c,d,a,b,7,14,0x676f02d9u); ZWZ_MD5_R2(b,c,d,a,12,20,0x8d2a4c8au); \
+    ZWZ_MD5_R3(a,b,c,d,5,4,0xfffa3942u); ZWZ_MD5_R3(d,a,b,c,8,11,0x8771f681u); ZWZ_MD5_R3(c,d,a,b,11,16,0x6d9d6122u); ZWZ_MD5_R3(b,c,d,a,14,23,0xfde5380cu); \
+    ZWZ_MD5_R3(a,b,c,d,1,4,0xa4beea44u); ZWZ_MD5_R3(d,a,b,c,4,11,0x4bdecfa9u); ZWZ_MD5_R3(c,d,a,b,7,16,0xf6bb4b60u); ZWZ_MD5_R3(b,c,d,a,10,23,0xbebfbc70u); \
+    ZWZ_MD5_R3(a,b,c,d,13,4,0x289b7ec6u); ZWZ_MD5_R3(d,a,b,c,0,11,0xeaa127fau); ZWZ_MD5_R3(c,d,a,b,3,16,0xd4ef3085u); ZWZ_MD5_R3(b,c,d,a,6,23,0x04881d05u); \
+    ZWZ_MD5_R3(a,b,c,d,9,4,0xd9d4d039u); ZWZ_MD5_R3(d,a,b,c,12,11,0xe6db99e5u); ZWZ_MD5_R3(c,d,a,b,15,16,0x1fa27cf8u); ZWZ_MD5_R3(b,c,d,a,2,23,0xc4ac5665u); \
+    ZWZ_MD5_R4(a,b,c,d,0,6,0xf4292244u); ZWZ_MD5_R4(d,a,b,c,7,10,0x432aff97u); ZWZ_MD5_R4(c,d,a,b,14,15,0xab9423a7u); ZWZ_MD5_R4(b,c,d,a,5,21,0xfc93a039u); \
+    ZWZ_MD5_R4(a,b,c,d,12,6,0x655b59c3u); ZWZ_MD5_R4(d,a,b,c,3,10,0x8f0ccc92u); ZWZ_MD5_R4(c,d,a,b,10,15,0xffeff47du); ZWZ_MD5_R4(b,c,d,a,1,21,0x85845dd1u); \
+    ZWZ_MD5_R4(a,b,c,d,8,6,0x6fa87e4fu); ZWZ_MD5_R4(d,a,b,c,15,10,0xfe2ce6e0u); ZWZ_MD5_R4(c,d,a,b,6,15,0xa3014314u); ZWZ_MD5_R4(b,c,d,a,13,21,0x4e0811a1u); \
+    ZWZ_MD5_R4(a,b,c,d,4,6,0xf7537e82u); ZWZ_MD5_R4(d,a,b,c,11,10,0xbd3af235u); ZWZ_MD5_R4(c,d,a,b,2,15,0x2ad7d2bbu); ZWZ_MD5_R4(b,c,d,a,9,21,0xeb86d391u);
+
 namespace zwz {
 
 struct Md5 {
@@ -17,30 +41,7 @@ struct Md5 {
         uint32_t w[16];
         memcpy(w, p, 64);  // little-endian host
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
-#define R1(a, b, c, d, k, s, t) a = b + rol(a + ((b & c) | (~b & d)) + w[k] + t, s)
-#define R2(a, b, c, d, k, s, t) a = b + rol(a + ((b & d) | (c & ~d)) + w[k] + t, s)
-#define R3(a, b, c, d, k, s, t) a = b + rol(a + (b ^ c ^ d) + w[k] + t, s)
-#define R4(a, b, c, d, k, s, t) a = b + rol(a + (c ^ (b | ~d)) + w[k] + t, s)
-        R1(a,b,c,d,0,7,0xd76aa478u); R1(d,a,b,c,1,12,0xe8c7b756u); R1(c,d,a,b,2,17,0x242070dbu); R1(b,c,d,a,3,22,0xc1bdceeeu);
-        R1(a,b,c,d,4,7,0xf57c0fafu); R1(d,a,b,c,5,12,0x4787c62au); R1(c,d,a,b,6,17,0xa8304613u); R1(b,c,d,a,7,22,0xfd469501u);
-        R1(a,b,c,d,8,7,0x698098d8u); R1(d,a,b,c,9,12,0x8b44f7afu); R1(c,d,a,b,10,17,0xffff5bb1u); R1(b,c,d,a,11,22,0x895cd7beu);
-        R1(a,b,c,d,12,7,0x6b901122u); R1(d,a,b,c,13,12,0xfd987193u); R1(c,d,a,b,14,17,0xa679438eu); R1(b,c,d,a,15,22,0x49b40821u);
-        R2(a,b,c,d,1,5,0xf61e2562u); R2(d,a,b,c,6,9,0xc040b340u); R2(c,d,a,b,11,14,0x265e5a51u); R2(b,c,d,a,0,20,0xe9b6c7aau);
-        R2(a,b,c,d,5,5,0xd62f105du); R2(d,a,b,c,10,9,0x02441453u); R2(c,d,a,b,15,14,0xd8a1e681u); R2(b,c,d,a,4,20,0xe7d3fbc8u);
-        R2(a,b,c,d,9,5,0x21e1cde6u); R2(d,a,b,c,14,9,0xc33707d6u); R2(c,d,a,b,3,14,0xf4d50d87u); R2(b,c,d,a,8,20,0x455a14edu);
-        R2(a,b,c,d,13,5,0xa9e3e905u); R2(d,a,b,c,2,9,0xfcefa3f8u); R2(c,d,a,b,7,14,0x676f02d9u); R2(b,c,d,a,12,20,0x8d2a4c8au);
-        R3(a,b,c,d,5,4,0xfffa3942u); R3(d,a,b,c,8,11,0x8771f681u); R3(c,d,a,b,11,16,0x6d9d6122u); R3(b,c,d,a,14,23,0xfde5380cu);
-        R3(a,b,c,d,1,4,0xa4beea44u); R3(d,a,b,c,4,11,0x4bdecfa9u); R3(c,d,a,b,7,16,0xf6bb4b60u); R3(b,c,d,a,10,23,0xbebfbc70u);
-        R3(a,b,c,d,13,4,0x289b7ec6u); R3(d,a,b,c,0,11,0xeaa127fau); R3(c,d,a,b,3,16,0xd4ef3085u); R3(b,c,d,a,6,23,0x04881d05u);
-        R3(a,b,c,d,9,4,0xd9d4d039u); R3(d,a,b,c,12,11,0xe6db99e5u); R3(c,d,a,b,15,16,0x1fa27cf8u); R3(b,c,d,a,2,23,0xc4ac5665u);
-        R4(a,b,c,d,0,6,0xf4292244u); R4(d,a,b,c,7,10,0x432aff97u); R4(c,d,a,b,14,15,0xab9423a7u); R4(b,c,d,a,5,21,0xfc93a039u);
-        R4(a,b,c,d,12,6,0x655b59c3u); R4(d,a,b,c,3,10,0x8f0ccc92u); R4(c,d,a,b,10,15,0xffeff47du); R4(b,c,d,a,1,21,0x85845dd1u);
-        R4(a,b,c,d,8,6,0x6fa87e4fu); R4(d,a,b,c,15,10,0xfe2ce6e0u); R4(c,d,a,b,6,15,0xa3014314u); R4(b,c,d,a,13,21,0x4e0811a1u);
-        R4(a,b,c,d,4,6,0xf7537e82u); R4(d,a,b,c,11,10,0xbd3af235u); R4(c,d,a,b,2,15,0x2ad7d2bbu); R4(b,c,d,a,9,21,0xeb86d391u);
-#undef R1
-#undef R2
-#undef R3
-#undef R4
+        ZWZ_MD5_STEPS
         h[0] += a; h[1] += b; h[2] += c; h[3] += d;
     }
     void update(const uint8_t* p, size_t n) {

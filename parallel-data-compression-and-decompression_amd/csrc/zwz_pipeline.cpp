@@ -107,6 +107,11 @@ struct Slices {
     uint64_t *h_off[2], *d_off[2];
     uint32_t *h_len[2], *h_olen[2], *h_st[2], *d_len[2], *d_olen[2], *d_st[2];
     hipEvent_t done[2] = {nullptr, nullptr};
+    // GPU MD5 of the files that lie whole inside a slice (zwz_md5_files_dev): (first slot, slots) per file in, 16 bytes out
+    uint32_t *h_files[2] = {nullptr, nullptr}, *d_files[2] = {nullptr, nullptr};
+    uint8_t *h_dig[2] = {nullptr, nullptr}, *d_dig[2] = {nullptr, nullptr};
+    uint32_t n_md5[2] = {0, 0};
+    void* md5_host = nullptr; void* md5_dev = nullptr;
 };
 
 int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
@@ -127,10 +132,23 @@ int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
         hipError_t e = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming);
         if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
     }
+    const size_t per = (size_t)cap * (8 + 16);                // a slice holds at most `cap` files
+    hipError_t e = hipHostMalloc(&s.md5_host, 2 * per, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&s.md5_dev, 2 * per);
+    if (e != hipSuccess) return hip_fail(e, "MD5 staging allocation");
+    for (int i = 0; i < 2; i++) {
+        uint8_t* hb = static_cast<uint8_t*>(s.md5_host) + i * per; uint8_t* db = static_cast<uint8_t*>(s.md5_dev) + i * per;
+        s.h_dig[i] = hb; s.h_files[i] = reinterpret_cast<uint32_t*>(hb + (size_t)cap * 16);
+        s.d_dig[i] = db; s.d_files[i] = reinterpret_cast<uint32_t*>(db + (size_t)cap * 16);
+    }
     return ZWZ_OK;
 }
 
-void free_slices(Slices& s) { for (auto& e : s.done) if (e) (void)hipEventDestroy(e); }
+void free_slices(Slices& s) {
+    for (auto& e : s.done) if (e) (void)hipEventDestroy(e);
+    if (s.md5_host) (void)hipHostFree(s.md5_host);
+    if (s.md5_dev) (void)hipFree(s.md5_dev);
+}
 
 }  // namespace
 
@@ -150,7 +168,8 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
     if (rank >= non_empty) return ZWZ_OK;   // main.cpp:47-51: this rank has nothing to do and creates no shard
 
     // this rank's files (compression.cpp:35-41); a file that cannot be opened is logged and skipped (:45-48)
-    struct File { std::string rel, full; int fd; uint64_t size; uint32_t first_chunk, nchunks; std::string md5; std::atomic<int>* md5_ready; };
+    struct File { std::string rel, full; int fd; uint64_t size; uint32_t first_chunk, nchunks; std::string md5; std::atomic<int>* md5_ready;
+                  int32_t gpu_md5 = -1; };   // index into its slice's GPU digest list, or -1: hashed on the host
     std::vector<File> files;
     uint64_t total_chunks = 0;
     for (size_t i = (size_t)rank; i < lines.size(); i += (size_t)nranks) {
@@ -208,20 +227,31 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         char hex[33]; m.hex(hex);
         files[fi].md5 = hex; files[fi].md5_ready->store(1);
     };
+    // a file that lies whole inside a slice is hashed on the GPU from the chunk slots the codec
+    // reads anyway (one lane per file); files cut by a slice boundary or read in pieces are hashed by host workers
+    // like before.  ZWZ_HOST_MD5=1 keeps everything on the host.
+    const bool gpu_md5 = getenv("ZWZ_HOST_MD5") == nullptr;
     auto start_read = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
         uint32_t g = g0;
+        sl.n_md5[b] = 0;
         while (g < g1) {
             const uint32_t fi = file_of(g);
-            const File& f = files[fi];
+            File& f = files[fi];
             const uint32_t c0 = g - f.first_chunk, c1 = std::min(f.nchunks, c0 + (g1 - g));
             const bool whole = c0 == 0 && c1 == f.nchunks;
             if (!whole && c0 == 0) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });
             // units of <= 64 chunks so that big files are read by several workers
             for (uint32_t u0 = c0; u0 < c1; u0 += 64) {
                 const uint32_t u1 = std::min(c1, u0 + 64);
-                const bool hash_here = whole && u0 == 0 && u1 == c1;
+                const bool one_unit = whole && u0 == 0 && u1 == c1;
+                if (one_unit && gpu_md5) {
+                    f.gpu_md5 = (int32_t)sl.n_md5[b];
+                    sl.h_files[b][2 * sl.n_md5[b]] = f.first_chunk - g0; sl.h_files[b][2 * sl.n_md5[b] + 1] = f.nchunks;
+                    sl.n_md5[b]++;
+                }
+                const bool hash_here = one_unit && !gpu_md5;
                 pool.submit(read_group[b], [&, fi, b, g0, u0, u1, hash_here] {
                     const File& ff = files[fi];
                     Md5 m;
@@ -259,6 +289,12 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         // offsets are relative to this slice's d_in
         int r = zwz_deflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b]);
         if (r) return r;
+        if (sl.n_md5[b]) {
+            HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, c->stream));
+            r = zwz_md5_files_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], sl.d_files[b], sl.n_md5[b], sl.d_dig[b]);
+            if (r) return r;
+            HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(sl.done[b], c->stream));
@@ -285,8 +321,16 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
             fwrite(sl.h_out[b] + (size_t)slot * ZWZ_DEV_STRIDE, 1, (size_t)payload, dest);
             if (payload == (int32_t)ZWZ_CHUNK_SIZE && sl.h_len[b][slot] >= 65510u) truncated++;
             if (last) {
-                while (!f.md5_ready->load()) std::this_thread::yield();
-                fwrite(f.md5.data(), 1, f.md5.size(), dest);
+                if (f.gpu_md5 >= 0) {
+                    static const char* dig = "0123456789abcdef";
+                    const uint8_t* d = sl.h_dig[b] + (size_t)f.gpu_md5 * 16;
+                    char hex[32];
+                    for (int i = 0; i < 16; i++) { hex[2 * i] = dig[d[i] >> 4]; hex[2 * i + 1] = dig[d[i] & 15]; }
+                    fwrite(hex, 1, 32, dest);
+                } else {
+                    while (!f.md5_ready->load()) std::this_thread::yield();
+                    fwrite(f.md5.data(), 1, f.md5.size(), dest);
+                }
             }
         }
     };

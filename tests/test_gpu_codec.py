@@ -113,6 +113,56 @@ def test_deflate_fuzz_large_and_mixed(codec, oracle):
     assert not wrong, wrong[:10]
 
 
+def test_md5_files_dev_matches_hashlib(codec):
+    """GPU MD5 of files laid out as 65 535-byte chunks in 65 536-byte slots, against hashlib:
+    every padding case (length mod 64 around 55/56/63/0), empty files, the empty trailing chunk of exact multiples,
+    words straddling a slot boundary."""
+    import hashlib
+    sizes = [0, 1, 3, 54, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 1000, 65534, 65535, 65536, 65535 * 2, 65535 * 2 + 1,
+             131071, 200000, 262144, 300001]
+    files = [corpus.random_bytes(7000 + i, n) if i % 2 else corpus.text_like(7000 + i, n) for i, n in enumerate(sizes)]
+    slots, lens, table = [], [], []
+    for data in files:
+        first = len(lens)
+        nchunks = len(data) // 65535 + 1                      # the reference's chunking: a short (possibly empty) last read
+        for ci in range(nchunks):
+            piece = data[ci * 65535:(ci + 1) * 65535]
+            slots.append(piece + bytes(65536 - len(piece))); lens.append(len(piece))
+        table += [first, nchunks]
+    # device buffers straight from the HIP runtime the library itself uses (torch is not needed for this path)
+    import ctypes
+    import numpy as np
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    class Dev:
+        def __init__(self, host):
+            self.n = host.nbytes
+            self.p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(self.p), max(self.n, 16)) == 0
+            assert hip.hipMemcpy(self.p, host.ctypes.data, self.n, 1) == 0      # hipMemcpyHostToDevice
+        def data_ptr(self):
+            return self.p.value
+        def numel(self):
+            return self.count
+    h_in = np.frombuffer(b"".join(slots), dtype=np.uint8)
+    d_in, d_off = Dev(h_in), Dev(np.arange(len(lens), dtype=np.uint64) * 65536)
+    d_len, d_files = Dev(np.array(lens, dtype=np.uint32)), Dev(np.array(table, dtype=np.uint32))
+    d_files.count = len(table)
+    h_dig = np.zeros(16 * len(files), dtype=np.uint8)
+    d_dig = Dev(h_dig)
+    codec.md5_files_dev(d_in, d_off, d_len, d_files, d_dig)
+    codec.sync()
+    assert hip.hipMemcpy(h_dig.ctypes.data, d_dig.p, h_dig.nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    for d in (d_in, d_off, d_len, d_files, d_dig):
+        hip.hipFree(d.p)
+    got = h_dig.tobytes()
+    for i, data in enumerate(files):
+        assert got[16 * i:16 * i + 16] == hashlib.md5(data).digest(), (i, len(data))
+
+
 def test_inflate_matches_oracle(codec, oracle):
     import zlib
     payloads, want = [], []
