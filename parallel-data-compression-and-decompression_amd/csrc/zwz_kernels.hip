@@ -40,22 +40,23 @@ static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_
 //           the finished links of the previous 2048 positions out of that buffer to HBM, both as
 //           16-byte vectors;
 //   wave 0 (inserter): per step one hash read, the head read / write / read-back, the collision
-//           check, one link write -- ~15 instructions.
+//           check, one link write -- 13 instructions.
 // The two meet at a barrier every 2048 positions (two buffers alternate).  Positions past the last
 // trigram get the out-of-range hash value 32768, whose "bucket" is a dummy slot behind the table:
 // the inserter needs no validity logic, the feeder zeroes those links on the way out.
 //
-// The inserter's steps are software-pipelined by hand: the three LDS operations of step s+1 are
-// issued before step s's read-back is looked at.  LDS returns in order, so "step s is back" is the
-// counter threshold lgkmcnt(3); the compiler's own wait insertion drains to 0 at loop headers, so
-// these LDS reads are issued from inline asm and waited for by hand.  What keeps that sound:
-//   * every step issues exactly three operations, preceded by the read of the next step's hashes;
-//   * a loaded register is not read before the wait that names it ("+v" ties the two);
-//   * two named register sets alternate, so no value crosses a copy while in flight.
-// A collision inside step s (lanes sharing a hash: one store wins, all read the old head) is then
-// repaired one step late, which adds two cases to the repair: lanes of step s+1 with the same hash
-// have read an arbitrary peer of s (they get the newest one, through `patch`), and the bucket is
-// rewritten only if s+1 did not already store a newer position in it.
+// The inserter's steady state is one block of inline asm (insert_block): three register sets take turns,
+// step t's three LDS operations and the hash read of step t+2 are issued before step t-2's read-back is
+// looked at, and "it is back" is a counted wait (LDS returns in order: lgkmcnt(10) = ten younger operations
+// may still be out).  The compiler's own wait insertion drains to 0 at loop headers and right behind loads
+// it schedules early, which is why this is asm; what keeps it sound:
+//   * every step issues exactly the same operations in the same order, whatever its lanes hold;
+//   * no in-flight register is read, copied or merged before the wait that covers it;
+//   * the loop is entered with nothing in flight and left through a full drain.
+// A collision inside a step (two lanes, one hash: 6 % of the steps on random bytes) is repaired in place
+// by the lane whose store lost (insert_block); anything more -- several losers, a later step holding the
+// same hash -- drains and goes through the general repair in C++, and blocks in which that keeps
+// happening (text) run a plain one-step-at-a-time loop instead (insert_block_dense).
 constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
 constexpr uint32_t kLinksNoHash = 32768;           // "hash" of a position without a trigram
 
