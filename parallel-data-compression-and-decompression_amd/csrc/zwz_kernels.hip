@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         }
     };
     auto write_link = [&](uint32_t slot, uint32_t prev) {   // the link replaces the hash in the buffer
-        asm volatile("ds_write_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(slot), "v"(prev) : "memory");
+        asm volatile("ds_write_b16 %0, %1" :: "v"(slot), "v"(prev) : "memory");     // no wait: LDS is in order, readers wait for themselves
     };
     uint32_t slow_exits = 0;                          // collisions of the last block that needed the general repair
     auto insert_block = [&](uint32_t k) {
@@ -188,13 +188,30 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         uint32_t s = 0;                                                                   // P0 = step s, P1 = step s + 1: issued, complete
         P0.p16 = first + lane; P1.p16 = P0.p16 + 64u; P2.p16 = P0.p16 + 128u;
         uint32_t h0 = 0, h1 = 0, h2 = 0;
-        issue_and_wait(P0, lds_u16(base));
-        if (n_steps > 1) issue_and_wait(P1, lds_u16(base + 128u));
+        bool primed = false;                                                              // hs0, hs1, h2, h0 hold the four hashes the loop starts from
+        uint32_t hs0 = 0, hs1 = 0, hs2 = 0;
+        if (n_steps >= 5u) {
+            // block start in two LDS round trips: the hashes of steps 0..3 at once, then steps 0 and 1 back to back
+            asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\t"
+                         "s_waitcnt lgkmcnt(0)" : "=&v"(hs0), "=&v"(hs1), "=&v"(h2), "=&v"(h0) : "v"(base) : "memory");
+            const uint32_t b0 = head_a + 2u * hs0, b1 = head_a + 2u * hs1;
+            asm volatile("ds_read_u16 %0, %4\n\tds_write_b16 %4, %6\n\tds_read_u16 %1, %4\n\t"
+                         "ds_read_u16 %2, %5\n\tds_write_b16 %5, %7\n\tds_read_u16 %3, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(P0.prev), "=&v"(P0.rb), "=&v"(P1.prev), "=&v"(P1.rb) : "v"(b0), "v"(b1), "v"(P0.p16), "v"(P1.p16) : "memory");
+            primed = true;
+        } else {
+            issue_and_wait(P0, lds_u16(base));
+            if (n_steps > 1) issue_and_wait(P1, lds_u16(base + 128u));
+        }
         for (;;) {
             uint32_t left = __builtin_amdgcn_readfirstlane(n_steps > s + 2u ? n_steps - 2u - s : 0u);   // steps not issued yet
             if (left < 3u) break;
-            uint32_t hs0 = lds_u16(base), hs1 = lds_u16(base + 128u), hs2 = 0;            // hashes of the steps in P0, P1 (still in their slots)
-            h2 = lds_u16(base + 256u); h0 = lds_u16(base + 384u);                         // ... and of the next two steps to issue
+            if (!primed) {
+                // (re-)entry after a general repair: hashes of the steps in P0, P1 (still in their slots) and of the next two to issue
+                asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(hs0), "=&v"(hs1), "=&v"(h2), "=&v"(h0) : "v"(base) : "memory");
+            }
+            primed = false;
             // Steady state, three steps a trip (three register sets take turns), entered with nothing in flight.  Per
             // step t: the hashes of step t+2 are read, the three operations of step t are issued, and only then is the
             // read-back of step t-2 looked at -- two steps of other work cover every LDS round trip.  LDS returns in
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         }
         repair(P0, base, false, P0, false, P0);
         write_link(base, P0.prev);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the feeder reads these links right after the barrier
     };
 
     // Collision-dense data (text: most steps hold several repeated trigrams): every step would leave the pipelined
