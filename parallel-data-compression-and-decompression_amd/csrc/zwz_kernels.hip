@@ -1531,7 +1531,24 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen);
             opos = __builtin_amdgcn_readfirstlane(opos);
             uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
-            for (uint32_t i = lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
+            // stored bytes: whole 16-byte vectors of output, each from five aligned input words shifted by the two
+            // ranges' relative misalignment (a 5-byte block header sits between them); bytes at the ragged ends singly.
+            // (One byte per lane per trip moved 1.7 TB/s with 5 k waves in flight; this is ~10x fewer instructions.)
+            {
+                const uint32_t head = min(cp, (16u - (opos & 15u)) & 15u);               // dst + opos + head is 16-byte aligned (dst is)
+                if (lane < head) dst[opos + lane] = src[soff + lane];
+                const uint32_t s0 = soff + head, d0 = opos + head, sh = s0 & 3u;
+                const uint32_t* sw = reinterpret_cast<const uint32_t*>(src + (s0 & ~3u));
+                uint32_t nvec = (cp - head) >> 4;
+                while (nvec && (s0 & ~3u) + 16u * nvec + 4u > nin16) nvec--;            // the fifth word must lie inside the readable extent
+                for (uint32_t v = lane; v < nvec; v += 64) {
+                    const uint32_t* q = sw + 4u * v;
+                    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                    *reinterpret_cast<uint4*>(dst + d0 + 16u * v) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                                                __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+                }
+                for (uint32_t i = head + 16u * nvec + lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
+            }
             uint32_t stop = 0;
             if (lane == 0) {
                 st.out_pos += cp;
