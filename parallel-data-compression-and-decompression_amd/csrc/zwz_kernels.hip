@@ -559,6 +559,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     // chain-heavy data (four of five positions have a chain predecessor: text) takes the sorted work order, sparse
     // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
     const bool sorted_order = link_stat[chunk] * 5u >= L * 4u;      // workgroup-uniform
+    for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
     uint32_t org = 0;
     ZWZ_PREFETCH(0u)
     for (uint32_t t = 0; t < ntiles; t++) {
@@ -590,8 +591,6 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             const uint32_t lg = 31u - (uint32_t)__builtin_clz(p - l2);
             return (lg > 13u ? 13u : lg) >> 1;
         };
-        for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of this tile (32-bit words)
-        __syncthreads();
         if (sorted_order) {
             // counts[bucket][trip][wave] -> exclusive scan -> destination of every position
             for (uint32_t kk = 0; kk < 16u; kk++) {
@@ -688,8 +687,10 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             drain();
         }
         __syncthreads();
-        for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads)
+        for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads) {
             hm[(ts >> 6) + i] = (uint64_t)s_has[2 * i] | ((uint64_t)s_has[2 * i + 1] << 32);
+            s_has[2 * i] = 0; s_has[2 * i + 1] = 0;                        // ready for the next tile (whoever read a word clears it)
+        }
         if (t + 1 == ntiles) break;
 
         // slide: the next tile starts at te and may look back 32506 positions
