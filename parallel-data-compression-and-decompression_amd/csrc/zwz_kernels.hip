@@ -1241,9 +1241,9 @@ static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpo
 
 // An incompressible chunk: every block is stored, so the stream is the input with a 2-byte zlib
 // header, a 5-byte header in front of each block and the Adler-32 behind.  No staging: one pass
-// over the input for the checksum (v_dot4 sums four bytes per instruction), one pass that writes
-// whole output dwords straight to HBM, each from one unaligned 4-byte read of the input except
-// the handful of dwords that touch a header.
+// over the input for the checksum (v_dot4 sums four bytes per instruction; skipped when the cap cuts
+// the checksum off), one pass that writes whole output dwords straight to HBM, each from one unaligned
+// 4-byte read of the input except the handful of dwords that touch a header.
 static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __restrict__ data, uint32_t L, uint32_t n_blocks,
                                                            const BlockInfo* __restrict__ bi, uint32_t* __restrict__ gout,
                                                            uint32_t* __restrict__ out_len_slot) {
@@ -1256,37 +1256,41 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
         for (uint32_t b = 0; b < n_blocks; b++) { s_hb[b] = hb; s_st[b] = bi[b].start; hb += 5u + (bi[b].end - bi[b].start); }
         for (uint32_t b = n_blocks; b <= kMaxBlocks; b++) { s_hb[b] = hb; s_st[b] = L; }   // s_hb[n_blocks] = where the Adler-32 goes
     }
-    // Adler-32: a = 1 + sum d_i, b = L + sum (L - i) d_i  (mod 65521); 16 dwords per thread, all in flight
     const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
-    uint32_t w[16];
-#pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-        w[u] = i < L ? d32[i >> 2] : 0u;                  // slot readable to L rounded up to 16
-    }
-    uint32_t a_sum = 0; unsigned long long b_sum = 0;
-#pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-        uint32_t x = w[u];
-        if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
-        const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
-        a_sum += sum;
-        b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
-    }
-    for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
-    if (lane_id() == 0) { s_a[tid >> 6] = a_sum; s_b[tid >> 6] = b_sum; }
     __syncthreads();
-    if (tid == 0) {
-        unsigned long long a = 1, b = L;
-        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_a[i]; b += s_b[i]; }
-        s_adler_be = __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
-        const uint32_t total = s_hb[n_blocks] + 4u;
-        *out_len_slot = total < kChunk ? total : kChunk;
+    // Adler-32: a = 1 + sum d_i, b = L + sum (L - i) d_i  (mod 65521); 16 dwords per thread, all in flight.
+    // Not for a chunk whose stream reaches the 65 535-byte cap before the trailer starts (every full incompressible
+    // chunk: 65 535 + 5 headers): the reference cuts the checksum off, so the input is read once, by the copy below.
+    if (s_hb[n_blocks] < kChunk) {                            // workgroup-uniform
+        uint32_t w[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16; u++) {
+            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+            w[u] = i < L ? d32[i >> 2] : 0u;                  // slot readable to L rounded up to 16
+        }
+        uint32_t a_sum = 0; unsigned long long b_sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 16; u++) {
+            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
+            uint32_t x = w[u];
+            if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
+            const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
+            a_sum += sum;
+            b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
+        }
+        for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
+        if (lane_id() == 0) { s_a[tid >> 6] = a_sum; s_b[tid >> 6] = b_sum; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long a = 1, b = L;
+            for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_a[i]; b += s_b[i]; }
+            s_adler_be = __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    if (tid == 0) { const uint32_t total = s_hb[n_blocks] + 4u; *out_len_slot = total < kChunk ? total : kChunk; }
     const uint32_t total = s_hb[n_blocks] + 4u, n_out = total < kChunk ? total : kChunk;
-    const uint32_t h1 = s_hb[1], h2 = s_hb[2], h3 = s_hb[3], h4 = s_hb[4], h_end = s_hb[n_blocks], adler_be = s_adler_be;
+    const uint32_t h1 = s_hb[1], h2 = s_hb[2], h3 = s_hb[3], h4 = s_hb[4], h_end = s_hb[n_blocks], adler_be = h_end < kChunk ? s_adler_be : 0u;
     auto block_at = [&](uint32_t x) { return (uint32_t)(x >= h1) + (uint32_t)(x >= h2) + (uint32_t)(x >= h3) + (uint32_t)(x >= h4); };   // unused slots hold h_end
     auto byte_at = [&](uint32_t x) -> uint32_t {
         if (x < 2u) return x ? 0x9cu : 0x78u;
@@ -1298,19 +1302,29 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
         if (off < 5u) { const uint32_t f = (len & 0xffffu) | ((~len & 0xffffu) << 16); return (f >> (8u * (off - 1u))) & 0xffu; }
         return data[s_st[b] + off - 5u];
     };
-    for (uint32_t o4 = tid; o4 < ((n_out + 3u) >> 2); o4 += kEncodeThreads) {
-        const uint32_t o = o4 * 4u;
+    // 16 output dwords per thread, every interior dword's two input words in flight before the first is used
+    // (one dword per trip waited out sixteen HBM round trips in a row once the checksum pass no longer warmed L2)
+    const uint32_t n_dw = (n_out + 3u) >> 2;
+    uint32_t q0[16], q1[16], sh[16]; bool fast[16];
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+        const uint32_t o = (tid + u * kEncodeThreads) * 4u;
         uint32_t b = block_at(o);
         if (b >= n_blocks) b = n_blocks - 1u;
         const uint32_t lo = s_hb[b] + 5u, hi = s_hb[b + 1];
+        fast[u] = (o >> 2) < n_dw && o >= lo && o + 4u <= hi && hi <= h_end;
+        const uint32_t p = fast[u] ? s_st[b] + (o - lo) : 0u;
+        sh[u] = p & 3u;
+        q0[u] = fast[u] ? d32[p >> 2] : 0u;
+        q1[u] = fast[u] && sh[u] ? d32[(p >> 2) + 1] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 16; u++) {
+        const uint32_t o4 = tid + u * kEncodeThreads, o = o4 * 4u;
+        if (o4 >= n_dw) continue;
         uint32_t v;
-        if (o >= lo && o + 4u <= hi && hi <= h_end) {
-            const uint32_t p = s_st[b] + (o - lo);
-            const uint32_t* q = d32 + (p >> 2);
-            v = (p & 3u) ? __builtin_amdgcn_alignbyte(q[1], q[0], p & 3u) : q[0];
-        } else {
-            v = byte_at(o) | byte_at(o + 1u) << 8 | byte_at(o + 2u) << 16 | byte_at(o + 3u) << 24;
-        }
+        if (fast[u]) v = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh[u]);
+        else v = byte_at(o) | byte_at(o + 1u) << 8 | byte_at(o + 2u) << 16 | byte_at(o + 3u) << 24;
         gout[o4] = v;
     }
 }
