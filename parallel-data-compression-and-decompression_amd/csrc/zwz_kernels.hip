@@ -29,6 +29,18 @@ namespace zwz {
 static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
+// Inclusive add-scan over the wave with DPP row shifts and broadcasts: six VALU instructions.  (`__shfl_up` is a
+// ds_bpermute -- an LDS-pipeline operation -- and the encoder scans once per 64 symbols with 32 waves on the CU.)
+static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // lz_links: link[p] = newest position q < p with hash3(q) == hash3(p), 0 if none (zlib NIL).
 // The chain insert is sequential in the position: one wave walks the chunk 64 positions a step with
@@ -1498,13 +1510,12 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
                     symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, e, byte, v, nb);
                 }
             }
-            uint32_t incl = nb;
-            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const uint32_t incl = wave_scan_incl(nb);
             if (nb) {
                 const EncBlock& eb = s_blk[blk];
                 lds_or_bits(s_out, (uint64_t)eb.body_pos + (running + incl - nb - eb.sym_bits_before), v, nb);
             }
-            running += __shfl(incl, 63);
+            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
 
