@@ -1549,6 +1549,8 @@ struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
+    uint16_t jump[64 * kWinSlots + 8];       // window offset -> offset of the symbol after the one starting there (pointer doubling)
+    uint32_t flag[64 * kWinSlots / 4];       // one byte per window offset: reached from offset 0
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
@@ -1678,41 +1680,101 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
                     inf[r] = kind | (nb << 3); val[r] = v;
                 }
-                // hop through the real symbol chain (wave-uniform)
-                uint32_t cur = 0, kcnt = 0, sv = 0, sp = 0, stop = 0xffu;
-                while (cur < 64u * kWinSlots && kcnt < kBatch) {
-                    const uint32_t ln = cur & 63u;
-                    uint32_t info = 0, v = 0;
+                // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
+                // A scalar loop hopping through it with v_readlane took ~50 SALU instructions a symbol, and a CU has ONE
+                // scalar issue slot a cycle for its 20 waves: 70 % of this kernel's time on text.  So the orbit is marked
+                // by pointer doubling over the 256 offsets (<= 8 rounds, usually 5), ranks and output positions come from
+                // ballots and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols,
+                // end of block, an error, a code for the sequential decoder) -- the same decisions in the same order
+                // of precedence as the loop they replace.
+                constexpr uint32_t kSink = 64u * kWinSlots;
+                uint32_t jr[kWinSlots];
+                uint8_t* flag8 = reinterpret_cast<uint8_t*>(m.flag);
+                m.flag[lane] = lane == 0 ? 1u : 0u;                       // offset 0 is reached by definition
 #pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++)      // wave-uniform select of the slot
-                        if ((cur >> 6) == r) { info = (uint32_t)__builtin_amdgcn_readlane((int)inf[r], ln); v = (uint32_t)__builtin_amdgcn_readlane((int)val[r], ln); }
-                    const uint32_t kind = info & 7u, nb = info >> 3;
-                    if (kind == kLit) {
-                        if (opos_u >= kChunk) { stop = kErr; stop_status = kInfOverflow; break; }
-                        if (lane == kcnt) { sv = v; sp = opos_u; }
-                        opos_u += 1u; kcnt++; cur += nb;
-                    } else if (kind == kMatch) {
-                        const uint32_t len = v >> 16, dist = v & 0xffffu;
-                        if (dist > opos_u) { stop = kErr; stop_status = kInfDataError; break; }          // too far back
-                        if (opos_u + len > kChunk) { stop = kErr; stop_status = kInfOverflow; break; }
-                        if (lane == kcnt) { sv = v; sp = opos_u; }
-                        opos_u += len; kcnt++; cur += nb;
-                    } else if (kind == kEob) { cur += nb; stop = kEob; break; }
-                    else { stop = kind; if (kind == kNeed) stop_status = kInfNeedInput; else if (kind == kErr) stop_status = kInfDataError; break; }
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    const uint32_t adv = r * 64u + lane + (inf[r] >> 3);
+                    jr[r] = (inf[r] & 7u) <= kMatch ? (adv < kSink ? adv : kSink) : kSink;      // only literals and matches lead on
+                    m.jump[r * 64u + lane] = (uint16_t)jr[r];
                 }
+                if (lane == 0) m.jump[kSink] = (uint16_t)kSink;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint64_t M[kWinSlots] = {1ull, 0ull, 0ull, 0ull};           // reached offsets, slot by slot (wave-uniform)
+                for (uint32_t round = 0; round < 8; round++) {
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++)                 // everything reached so far marks what lies 2^round symbols on
+                        if (((M[r] >> lane) & 1ull) && jr[r] < kSink) flag8[jr[r]] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    bool grown = false;
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) {
+                        const uint64_t now = __ballot(flag8[r * 64u + lane] != 0);
+                        grown = grown || now != M[r];
+                        M[r] = now;
+                    }
+                    if (!grown) break;
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) jr[r] = m.jump[jr[r]];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) m.jump[r * 64u + lane] = (uint16_t)jr[r];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                // Ranks (symbol index in the batch) and output positions of the reached offsets, in window order; the first
+                // reached offset at which the batch must end decides how the round ends.  Symbols go into the batch arrays
+                // as they are ranked; the entries from the end of the batch on are blanked afterwards.
+                m.pos[lane] = 0xffffffffu;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t base = 0, carry = 0, cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
+                bool ended = false;
+#pragma unroll
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    const uint32_t kd = inf[r] & 7u;
+                    const bool mk = (M[r] >> lane) & 1ull;
+                    const uint32_t rank = base + (uint32_t)__popcll(M[r] & lanes_below());
+                    const uint32_t ol = !mk ? 0u : kd == kLit ? 1u : kd == kMatch ? val[r] >> 16 : 0u;
+                    const uint32_t sc = wave_scan_incl(ol);
+                    const uint32_t pos = opos_u + carry + sc - ol;
+                    const bool ends = mk && (rank >= kBatch || kd >= kEob || (kd == kLit && pos >= kChunk) ||
+                                             (kd == kMatch && ((val[r] & 0xffffu) > pos || pos + (val[r] >> 16) > kChunk)));
+                    if (mk && !ends && rank < kBatch) { m.batch[rank] = val[r]; m.pos[rank] = pos; }
+                    const uint64_t C = __ballot(ends);
+                    if (!ended && C) {                                     // wave-uniform: the round ends at this offset
+                        ended = true;
+                        const uint32_t lc = (uint32_t)__builtin_ctzll(C);
+                        const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_rank = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)lc);
+                        const uint32_t c_val = (uint32_t)__builtin_amdgcn_readlane((int)val[r], (int)lc);
+                        opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
+                        cur = r * 64u + lc;
+                        k = c_rank < kBatch ? c_rank : kBatch;
+                        if (c_rank >= kBatch) { /* batch full: the next round starts at this symbol */ }
+                        else if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
+                        else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
+                        else if (c_kind == kEob) { cur += (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)lc); stop = kEob; }
+                        else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
+                    }
+                    if (!ended && M[r]) {                                  // so far plain symbols: the chain leaves the window behind the last of them
+                        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(M[r]);
+                        cur = r * 64u + ll + (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)ll);
+                    }
+                    base += (uint32_t)__popcll(M[r]);
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                }
+                if (!ended) { k = base; opos_new = opos_u + carry; }
                 bp += cur;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane >= k) m.pos[lane] = 0xffffffffu;                  // symbols ranked behind the end of the batch do not belong to it
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // The wave moves the bytes of this batch, one output byte per lane per trip: find the
                 // symbol that produces the byte (binary search over the batch's start offsets), follow
                 // back-references that point into this same batch until they land on a literal of the
                 // batch or on output of an earlier batch, then load/store.  All loads of a trip are in
                 // flight together (copying match by match cost one L2 round trip per match: ~9 ms a chunk).
-                const uint32_t k = kcnt;
-                const uint32_t bstart = __builtin_amdgcn_readfirstlane(k ? (uint32_t)__builtin_amdgcn_readlane((int)sp, 0) : opos_u);
-                const uint32_t bbytes = opos_u - bstart;
-                // the batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
-                // owners here; indexed LDS reads are also cheaper than eight bpermutes)
-                m.batch[lane] = sv; m.pos[lane] = lane < k ? sp : 0xffffffffu;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // The batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
+                // owners here; indexed LDS reads are also cheaper than eight bpermutes).
+                const uint32_t bstart = opos_u;
+                const uint32_t bbytes = opos_new - bstart;
+                opos_u = opos_new;
                 auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
                     uint32_t lo = 0;
 #pragma unroll
