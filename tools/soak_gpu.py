@@ -41,5 +41,31 @@ for i, (c, g, b) in enumerate(zip(chunks, got, back)):
         bad += 1; print("DEFLATE MISMATCH", i, len(c)); open("/tmp/soak_bad_%d.bin" % i, "wb").write(c)
     elif b != o.inflate(g, 70000)[0]:
         bad += 1; print("INFLATE MISMATCH", i, len(c))
+# corrupted and truncated streams: the decoder must stop exactly where the reference's ignored-return-code inflate does
+import zlib
+rs2 = corpus.splitmix64(seed + 77, 4 * N)
+bad_payloads = []
+for i in range(min(N, 4000)):
+    z = bytearray(got[i]) if len(got[i]) > 8 else bytearray(zlib.compress(b"abcabcabc" * 50, 6))
+    mode = int(rs2[4 * i] % 4)
+    if mode == 0:
+        z[2 + int(rs2[4 * i + 1] % (len(z) - 2))] ^= 1 << int(rs2[4 * i + 2] % 8)
+    elif mode == 1:
+        z = z[:2 + int(rs2[4 * i + 1] % (len(z) - 2))]
+    elif mode == 2:
+        for j in range(3):
+            z[2 + int((rs2[4 * i + 1] >> (11 * j)) % (len(z) - 2))] ^= 0xff
+    else:
+        z += bytes(min(int(rs2[4 * i + 1] % 7), 65535 - len(z)))
+    bad_payloads.append(bytes(z))
+t2 = time.time()
+gb, _ = codec.inflate_chunks(bad_payloads)
+nbad = 0
+for i, (pl, g) in enumerate(zip(bad_payloads, gb)):
+    w, total, st = o.inflate(pl, 1 << 20)
+    if total <= 65535 and g != w:
+        nbad += 1; bad += 1
+        if nbad < 5: print("CORRUPT-STREAM MISMATCH", i, len(pl), len(g), len(w))
+print("corrupt streams: %d checked, %d mismatches" % (len(bad_payloads), nbad))
 print("soak: %d chunks, %d bytes, gpu %.1f s, oracle %.1f s, mismatches %d" % (N, sum(map(len, chunks)), t1 - t0, time.time() - t1, bad))
 sys.exit(1 if bad else 0)
