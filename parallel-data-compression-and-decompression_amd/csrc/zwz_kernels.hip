@@ -1729,16 +1729,19 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 bool ended = false;
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
+                    // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow,
+                    // ~100 scalar instructions per slot -- and the scalar unit is what this kernel runs out of)
                     const uint32_t kd = inf[r] & 7u;
-                    const bool mk = (M[r] >> lane) & 1ull;
+                    const uint32_t mk = (uint32_t)(M[r] >> lane) & 1u;
                     const uint32_t rank = base + (uint32_t)__popcll(M[r] & lanes_below());
-                    const uint32_t ol = !mk ? 0u : kd == kLit ? 1u : kd == kMatch ? val[r] >> 16 : 0u;
+                    const uint32_t is_lit = (uint32_t)(kd == kLit), is_match = (uint32_t)(kd == kMatch), mlen = val[r] >> 16;
+                    const uint32_t ol = mk * (is_lit + is_match * mlen);
                     const uint32_t sc = wave_scan_incl(ol);
                     const uint32_t pos = opos_u + carry + sc - ol;
-                    const bool ends = mk && (rank >= kBatch || kd >= kEob || (kd == kLit && pos >= kChunk) ||
-                                             (kd == kMatch && ((val[r] & 0xffffu) > pos || pos + (val[r] >> 16) > kChunk)));
-                    if (mk && !ends && rank < kBatch) { m.batch[rank] = val[r]; m.pos[rank] = pos; }
-                    const uint64_t C = __ballot(ends);
+                    const uint32_t ends = mk & ((uint32_t)(rank >= kBatch) | (uint32_t)(kd >= kEob) | (is_lit & (uint32_t)(pos >= kChunk)) |
+                                                (is_match & ((uint32_t)((val[r] & 0xffffu) > pos) | (uint32_t)(pos + mlen > kChunk))));
+                    if (mk & (ends ^ 1u)) { m.batch[rank] = val[r]; m.pos[rank] = pos; }      // not at an end implies rank < kBatch
+                    const uint64_t C = __ballot(ends != 0);
                     if (!ended && C) {                                     // wave-uniform: the round ends at this offset
                         ended = true;
                         const uint32_t lc = (uint32_t)__builtin_ctzll(C);
