@@ -2,18 +2,21 @@
 // compression.cpp:119-134 and decompression.cpp:16-36, rebuilt as a batch pipeline over HBM).
 //
 // Compress, per batch of chunks (stage -> intermediate in HBM -> next stage):
-//   lz_links    one wave / chunk      15-bit hash + newest-first chain links (zlib's head/prev),
-//                                     64 positions per step, LDS head table, ballot de-duplication
-//   lz_match    one WG / 16 Ki tile   per-position best-of-32 / best-of-128 match records; the
-//                                     32 KiB history window (bytes + links) staged in LDS
-//   lz_parse    one lane / chunk      lazy-evaluation walk over the records -> symbol bit masks
+//   lz_links    2 waves / chunk       15-bit hash + newest-first chain links (zlib's head/prev): a feeder wave
+//                                     hashes and streams, an inserter wave walks the LDS head table
+//   lz_match    one WG / chunk        per-position best-of-32 / best-of-128 match records; the 32 KiB history
+//                                     window (bytes + links) lives in LDS and slides tile by tile
+//   lz_parse    one wave / chunk      lazy-evaluation walk over the records, block-parallel -> symbol bit masks
 //   blockify    one WG / chunk        symbol ranks (popcount prefix), 16383-symbol block cuts,
 //                                     per-block histograms (LDS atomics)
-//   plan        one wave / block      zlib-exact Huffman trees, stored/static/dynamic choice, header
-//   encode      one WG / chunk        code lengths -> prefix scan -> bit offsets -> LDS bit packing,
-//                                     stored-block byte copy, Adler-32, 65535-byte truncation
+//   plan_probe / plan_cost / plan     stored / static settled by an optimal-Huffman-cost lower bound (wave per
+//                                     block sorts, lane per block merges); the rest get zlib-exact trees
+//   encode      one WG / chunk        code lengths -> prefix scan -> bit offsets -> LDS bit packing; stored
+//                                     chunks copied straight through; Adler-32, 65535-byte truncation
 // Decompress:
-//   inflate     one wave / chunk      lane 0 decodes symbol batches, the wave moves the bytes
+//   inflate     one wave / chunk      window-parallel Huffman decode, byte-parallel copies
+// Integrity:
+//   md5_files   one lane / file       RFC 1321 over a file's chunk slots
 //
 // All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
 #include <hip/hip_runtime.h>
@@ -1035,7 +1038,8 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 // ------------------------------------------------------------------------------------------------
 // plan, in three launches.
 //   plan_probe (one wave per block): the stored-block shortcut's parallel half -- exact static_len /
-//       extra bits / used codes, and both histograms rank-sorted ascending -> BlockProbe.
+//       extra bits / used codes, and both histograms sorted ascending (by counting when every count is
+//       small, else by rank) -> BlockProbe.
 //   plan_cost  (one LANE per block): the optimal Huffman cost of the sorted counts by two-queue
 //       merge, 64 blocks per wave, then huff_core.h's shortcut_type.  The merge is a chain of
 //       ~m dependent steps; a wave per block spends them on one lane (and on the CU's one scalar
@@ -1538,10 +1542,11 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// inflate: one wave per chunk.  Lane 0 owns the bit reader and the tables; the wave moves bytes.
-// The payload reaches lane 0 through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave
-// (16 bytes per lane, coalesced): a decode call consumes < 1 KiB, so topping the ring up to
-// pos + 1 KiB before every call keeps lane 0 off global memory entirely.
+// inflate: one wave per chunk.  Lane 0 owns block headers and table construction; symbols are decoded by the
+// whole wave from a window of the bit stream (see the Huffman branch below) and the wave moves the bytes.
+// The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane,
+// coalesced): a round consumes < 1 KiB, so topping the ring up to pos + 1 KiB before every round keeps the
+// decoders off global memory entirely.
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
 
