@@ -673,28 +673,33 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             };
             for (uint32_t k0 = 0; k0 < 16u; k0 += 4u) {
                 if (nl + 256u > kListCap) drain();
-                uint32_t q[4], l1[4], scan[4]; bool ok[4];
+                // (flags as 0/1 words and unconditional reads at clamped indices: as bool tests and guarded reads this pass was
+                // mostly exec-mask bookkeeping on the CU's one scalar unit)
+                uint32_t q[4], l1[4], scan[4], ok[4], pi[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     q[u] = wave * 1024u + (k0 + u) * 64u + lane;
                     const uint32_t p = ts + q[u];
-                    ok[u] = q[u] < npos && p + kMinMatch <= L;
-                    l1[u] = ok[u] ? (uint32_t)slink[p - org] : 0u;
-                    scan[u] = ok[u] ? load_u32(sdata, p - org) : 0u;
+                    ok[u] = (uint32_t)(q[u] < npos) & (uint32_t)(p + kMinMatch <= L);
+                    pi[u] = ok[u] ? p - org : ts - org;                       // a readable stand-in for positions out of play
+                    l1[u] = slink[pi[u]];
+                    scan[u] = load_u32(sdata, pi[u]);
                 }
                 uint32_t l2[4], cw[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     const uint32_t p = ts + q[u];
-                    ok[u] = ok[u] && l1[u] != 0 && p - l1[u] <= kMaxDist && !(p >= kSlidePos && l1[u] <= kWSize);   // lz_search's own entry test
-                    l2[u] = ok[u] ? (uint32_t)slink[l1[u] - org] : 0u;
-                    cw[u] = ok[u] ? load_u32(sdata, l1[u] - org) : 0u;
+                    ok[u] &= (uint32_t)(l1[u] != 0) & (uint32_t)(p - l1[u] <= kMaxDist) &
+                             (((uint32_t)(p >= kSlidePos) & (uint32_t)(l1[u] <= kWSize)) ^ 1u);    // lz_search's own entry test
+                    const uint32_t li = ok[u] ? l1[u] - org : pi[u];
+                    l2[u] = slink[li];
+                    cw[u] = load_u32(sdata, li);
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     const uint32_t p = ts + q[u], limit = p > kMaxDist ? p - kMaxDist : 0u;
-                    const bool push = ok[u] && (l2[u] > limit || ((cw[u] ^ scan[u]) & 0xffffffu) == 0u);
-                    const uint64_t m = __ballot(push);
+                    const uint32_t push = ok[u] & ((uint32_t)(l2[u] > limit) | (uint32_t)(((cw[u] ^ scan[u]) & 0xffffffu) == 0u));
+                    const uint64_t m = __ballot(push != 0);
                     if (push) wl[nl + (uint32_t)__popcll(m & lanes_below())] = (uint16_t)q[u];
                     nl += (uint32_t)__popcll(m);
                 }
