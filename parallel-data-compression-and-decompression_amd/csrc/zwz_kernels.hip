@@ -1001,7 +1001,13 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
             const uint32_t pg = (g0 + u * kBlockifyThreads) << 4;
             const uint32_t b_lo = block_of(pg), b_hi = block_of(pg + 15u);
             const uint32_t wd[4] = {bytes[u].x, bytes[u].y, bytes[u].z, bytes[u].w};
-            if (lits[u]) {
+            if (__ballot(lits[u] != 0xffffu || b_lo != b_hi) == 0) {
+                // every lane: sixteen literals of one block (incompressible data, nearly always) -- no per-position tests,
+                // which are sixteen rounds of exec-mask bookkeeping on the scalar unit
+                uint32_t* h = s_hist[b_lo];
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) atomicAdd(&h[(wd[j >> 2] >> ((j & 3u) * 8u)) & 0xffu], 1u);
+            } else if (lits[u]) {
 #pragma unroll
                 for (uint32_t j = 0; j < 16; j++) {
                     if (!((lits[u] >> j) & 1u)) continue;
