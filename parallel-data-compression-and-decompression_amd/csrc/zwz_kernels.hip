@@ -497,8 +497,10 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
             if (hit == 0) break;                                                                    \
             if ((hit >> lane) & 1ull) {                                                             \
                 const uint32_t c_ = cur - org;                                                      \
-                const uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;\
-                uint32_t len = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;\
+                uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;    \
+                asm volatile("" : "+v"(x0), "+v"(x1));   /* both words now: left alone, the second read is sunk behind a branch on the first */\
+                const uint32_t l0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, l1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3);\
+                uint32_t len = x0 ? l0 : x1 ? l1 : 8u;                                              \
                 if (len == 8u) len = match_len_from(data, c_, pp, 8u, max_len);                     \
                 len = len < max_len ? len : max_len;                                                \
                 if (len > best) {                                                                   \
