@@ -56,9 +56,11 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 //           16-byte vectors;
 //   wave 0 (inserter): per step one hash read, the head read / write / read-back, the collision
 //           check, one link write -- 13 instructions.
-// The two meet at a barrier every 2048 positions (two buffers alternate).  Positions past the last
-// trigram get the out-of-range hash value 32768, whose "bucket" is a dummy slot behind the table:
-// the inserter needs no validity logic, the feeder zeroes those links on the way out.
+// The two meet at a barrier every 2048 positions (two buffers alternate).  What the feeder hands over is
+// each position's bucket ADDRESS (2 x hash: one instruction less on the inserter's critical path).
+// Positions past the last trigram are sent to bucket 0: they are the last positions of the chunk, nothing
+// reads the table after them, and the feeder zeroes their links on the way out -- so the inserter needs
+// no validity logic.
 //
 // The inserter's steady state is one block of inline asm (insert_block): three register sets take turns,
 // step t's three LDS operations and the hash read of step t+2 are issued before step t-2's read-back is
@@ -73,7 +75,7 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // same hash -- drains and goes through the general repair in C++, and blocks in which that keeps
 // happening (text) run a plain one-step-at-a-time loop instead (insert_block_dense).
 constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
-constexpr uint32_t kLinksNoHash = 32768;           // "hash" of a position without a trigram
+constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (see below: any bucket will do)
 
 __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         if (o + 32u <= Lr) in_b = g[1];
         if (o + 36u <= Lr) in_c = reinterpret_cast<const uint32_t*>(data + o)[8];
     };
+    typedef __attribute__((address_space(3))) uint8_t* lds_byte_ptr;
+    const uint32_t head_base = (uint32_t)(uintptr_t)(lds_byte_ptr) reinterpret_cast<uint8_t*>(head);   // 0: this kernel has no static LDS
     auto hash_block = [&](uint32_t k) {            // hashes of positions [2048 k, 2048 k + 2048) from the loaded input: 32 per lane
         const uint32_t o = k * kLinksBlock + lane * 32u;
         const uint32_t w[9] = {in_a.x, in_a.y, in_a.z, in_a.w, in_b.x, in_b.y, in_b.z, in_b.w, in_c};
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3u) : w[i >> 2];
             uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
             if (i >= n_ok) h = kLinksNoHash;
+            h = 2u * h + head_base;                    // the bucket's LDS byte address (fits 16 bits: the head table starts at LDS address 0)
             if (i & 1u) packed[i >> 1] |= h << 16; else packed[i >> 1] = h;
         }
         uint4* dst = reinterpret_cast<uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         return v;
     };
     auto issue_and_wait = [&](Step& S, uint32_t h) {   // the slow path's version of a step's three operations
-        const uint32_t bucket = head_a + 2u * h;
+        const uint32_t bucket = h;                    // the buffer holds bucket addresses
         asm volatile("ds_read_u16 %0, %2\n\tds_write_b16 %2, %3\n\tds_read_u16 %1, %2\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(S.prev), "=&v"(S.rb) : "v"(bucket), "v"(S.p16) : "memory");
     };
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             const uint64_t a1 = __builtin_amdgcn_uicmp(h_1, hh, 32), a2 = __builtin_amdgcn_uicmp(h_2, hh, 32);
             if (a1) { if (lane == (uint32_t)__builtin_ctzll(a1)) N1.prev = newest; }
             else if (a2) { if (lane == (uint32_t)__builtin_ctzll(a2)) N2.prev = newest; }
-            else if (lane == top) head[hh] = (uint16_t)newest;                    // newest peer owns the bucket
+            else if (lane == top) head[(hh - head_a) >> 1] = (uint16_t)newest;    // newest peer owns the bucket (hh is its byte address)
             dup &= ~peers;
         }
     };
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             // block start in two LDS round trips: the hashes of steps 0..3 at once, then steps 0 and 1 back to back
             asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\t"
                          "s_waitcnt lgkmcnt(0)" : "=&v"(hs0), "=&v"(hs1), "=&v"(h2), "=&v"(h0) : "v"(base) : "memory");
-            const uint32_t b0 = head_a + 2u * hs0, b1 = head_a + 2u * hs1;
+            const uint32_t b0 = hs0, b1 = hs1;
             asm volatile("ds_read_u16 %0, %4\n\tds_write_b16 %4, %6\n\tds_read_u16 %1, %4\n\t"
                          "ds_read_u16 %2, %5\n\tds_write_b16 %5, %7\n\tds_read_u16 %3, %5\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(P0.prev), "=&v"(P0.rb), "=&v"(P1.prev), "=&v"(P1.rb) : "v"(b0), "v"(b1), "v"(P0.p16), "v"(P1.p16) : "memory");
@@ -242,11 +247,10 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 #define ZWZ_LINK_STEP(HN, HN_OFF, HC, HSC, PC, RC, PPOS, PR, RR, RPOS, ROFF, FIX, BACK)              \
                 "ds_read_u16 %[" HN "], %[base] offset:" HN_OFF "\n\t"                                 \
                 "s_waitcnt lgkmcnt(10)\n\t"                                                          \
-                "v_lshl_add_u32 %[bk], %[" HC "], 1, %[head]\n\t"                                    \
                 "v_mov_b32 %[" HSC "], %[" HC "]\n\t"                                                \
-                "ds_read_u16 %[" PC "], %[bk]\n\t"                                                   \
-                "ds_write_b16 %[bk], %[" PPOS "]\n\t"                                                \
-                "ds_read_u16 %[" RC "], %[bk]\n\t"                                                   \
+                "ds_read_u16 %[" PC "], %[" HSC "]\n\t"                                              \
+                "ds_write_b16 %[" HSC "], %[" PPOS "]\n\t"                                           \
+                "ds_read_u16 %[" RC "], %[" HSC "]\n\t"                                                   \
                 "s_waitcnt lgkmcnt(10)\n\t"                                                          \
                 "v_cmp_ne_u32 vcc, %[" RR "], %[" RPOS "]\n\t"                                       \
                 "s_cbranch_vccnz " FIX "f\n\t"                                                       \
@@ -276,8 +280,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 "s_and_b64 exec, %[dm], vcc\n\t"                                                     \
                 "ds_write_b16 %[bk], %[" RPOS "] offset:" ROFF "\n\t"                                \
                 "s_andn2_b64 exec, %[dm], vcc\n\t"                                                   \
-                "v_lshl_add_u32 %[bk], %[" HSR "], 1, %[head]\n\t"                                   \
-                "ds_write_b16 %[bk], %[" RPOS "]\n\t"                                                \
+                "ds_write_b16 %[" HSR "], %[" RPOS "]\n\t"                                                \
                 "s_mov_b64 exec, %[sv]\n\t"                                                          \
                 "s_branch " BACK "b\n\t"
             asm volatile(
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         uint32_t h = lds_u16(base), collided = 0;
         for (uint32_t st = 0; st < n_steps; st++) {
             uint32_t hn;
-            const uint32_t bucket = head_a + 2u * h;
+            const uint32_t bucket = h;
             asm volatile("ds_read_u16 %0, %3 offset:128\n\tds_read_u16 %1, %4\n\tds_write_b16 %4, %5\n\tds_read_u16 %2, %4\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(hn), "=&v"(P.prev), "=&v"(P.rb) : "v"(base), "v"(bucket), "v"(P.p16) : "memory");
             uint64_t dup = __builtin_amdgcn_uicmp(P.rb, P.p16, 33 /* ICMP_NE */);
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                     if (h == hh) {
                         const uint64_t lower = peers & lanes_below();
                         if (lower) P.prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
-                        if (lane == top) head[hh] = (uint16_t)P.p16;              // newest peer owns the bucket
+                        if (lane == top) head[(hh - head_a) >> 1] = (uint16_t)P.p16;   // newest peer owns the bucket
                     }
                     dup &= ~peers;
                 }
