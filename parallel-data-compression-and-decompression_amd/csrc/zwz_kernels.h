@@ -58,6 +58,9 @@ struct BlockProbe {
 };
 static_assert(sizeof(BlockProbe) == 32 + 640, "BlockProbe layout");
 
+constexpr uint32_t kChosenOffset = 4096;   // bytes into a chunk's link array
+static_assert(kMaxBlocks * sizeof(BlockProbe) <= kChosenOffset && kChosenOffset + 21846 * 4 <= kLinkStride * 2, "links space: probes, then chosen records");
+
 struct DeflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned
     uint8_t* out; uint64_t out_stride; uint32_t* out_len;                            // out_stride % 4 == 0, >= 65536
@@ -67,6 +70,8 @@ struct DeflateArgs {
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // kMaxBlocks per chunk; aliases `links`, which is dead once lz_match has run
+    // The chosen record of every match symbol, compact and in stream order (lz_parse -> blockify, encode): a chunk's
+    // array also lives in its dead `links` space, kChosenOffset bytes in (behind the probes), < 21 846 entries.
 };
 
 struct InflateArgs {

@@ -32,6 +32,10 @@ namespace zwz {
 static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
+static __device__ __forceinline__ uint32_t* chosen_of(const uint16_t* links, uint32_t chunk) {
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(links + (size_t)chunk * kLinkStride)) + kChosenOffset);
+}
+
 // Inclusive add-scan over the wave with DPP row shifts and broadcasts: six VALU instructions.  (`__shfl_up` is a
 // ds_bpermute -- an LDS-pipeline operation -- and the encoder scans once per 64 symbols with 32 waves on the CU.)
 static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
@@ -763,7 +767,7 @@ struct ParseWaveMem {
 __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n,
                                                                 const uint2* __restrict__ entries, const uint64_t* __restrict__ has128,
                                                                 uint64_t* __restrict__ sym, uint64_t* __restrict__ mst,
-                                                                uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info) {
+                                                                uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info, uint16_t* __restrict__ links) {
     __shared__ ParseWaveMem s_mem[kParseThreads / 64];
     const uint32_t chunk = blockIdx.x * (kParseThreads / 64) + (threadIdx.x >> 6);
     if (chunk >= n) return;
@@ -804,6 +808,8 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     uint64_t hw_cur = hw_pre;                        // has128 word of the block being processed
     pre = fetch(1);
     uint32_t carry_open = 0, n_sym = 0, last_is_match = 0;
+    uint32_t* chosen = chosen_of(links, chunk);      // the chosen record of every match, compact, in stream order
+    uint32_t n_match = 0;                            // wave-uniform
     auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t { const uint2 e = m.win[p & 127u]; return sel ? e.y : e.x; };
 
     for (uint32_t blk = 0; blk < nwords; blk++) {
@@ -905,6 +911,13 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         const uint64_t sym_w = ~cover & validm;
         n_sym += (uint32_t)__popcll(sym_w);
         if (lane == 0) { gsym[blk] = sym_w; gmst[blk] = M; gm32[blk] = M32; }
+        if (M) {                                     // this block's match starts are final: their records go out, selected and compact
+            if ((M >> lane) & 1ull) {
+                const uint2 e = m.win[q & 127u];
+                chosen[n_match + (uint32_t)__popcll(M & lanes_below())] = ((M32 >> lane) & 1ull) ? e.y : e.x;
+            }
+            n_match += (uint32_t)__popcll(M);
+        }
         if (lane < 2) { m.ring_r[slot + lane] = 0; m.ring_s[slot + lane] = 0; m.ring_m[slot + lane] = 0; m.ring_m32[slot + lane] = 0; }
     }
     if (lane == 0) {
@@ -927,9 +940,11 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
                                                                    const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                    const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
                                                                    const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
-                                                                   BlockInfo* __restrict__ blocks) {
+                                                                   BlockInfo* __restrict__ blocks, const uint16_t* __restrict__ links) {
     __shared__ uint64_t s_sym[kMaskWords];
     __shared__ uint32_t s_rank[kMaskWords + 1];   // symbols before word w
+    __shared__ uint16_t s_mrank[kMaskWords];      // matches before word w (< 21 846)
+    __shared__ uint32_t s_msum[kBlockifyThreads / 64];
     __shared__ uint32_t s_hist[kMaxBlocks][kLCodes + kDCodes + 4];
     __shared__ uint32_t s_wsum[kBlockifyThreads / 64];
     __shared__ uint32_t s_start[kMaxBlocks + 1], s_flush[kMaxBlocks];
@@ -939,7 +954,6 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
     const ChunkInfo ci = info[chunk];
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
-    const uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
 
     for (uint32_t i = tid; i < kMaxBlocks * (kLCodes + kDCodes + 4); i += kBlockifyThreads) (&s_hist[0][0])[i] = 0;
     if (tid <= kMaxBlocks) s_start[tid] = L;
@@ -953,14 +967,15 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
         s_sym[wi] = w[k];
         c[k] = (uint32_t)__popcll(w[k]); tsum += c[k];
     }
-    uint32_t incl = tsum;
-    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d); if (lane_id() >= d) incl += v; }
-    if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+    uint32_t cm[kPer], msum = 0;                  // the same prefix over the match-start mask: a match's index into `chosen`
+    for (uint32_t k = 0; k < kPer; k++) { const uint32_t wi = tid * kPer + k; cm[k] = wi < nwords ? (uint32_t)__popcll(gmst[wi]) : 0u; msum += cm[k]; }
+    const uint32_t incl = wave_scan_incl(tsum), mincl = wave_scan_incl(msum);
+    if (lane_id() == 63) { s_wsum[tid >> 6] = incl; s_msum[tid >> 6] = mincl; }
     __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t i = 0; i < (tid >> 6); i++) wbase += s_wsum[i];
-    uint32_t run = wbase + incl - tsum;
-    for (uint32_t k = 0; k < kPer; k++) { s_rank[tid * kPer + k] = run; run += c[k]; }
+    uint32_t wbase = 0, mbase = 0;
+    for (uint32_t i = 0; i < (tid >> 6); i++) { wbase += s_wsum[i]; mbase += s_msum[i]; }
+    uint32_t run = wbase + incl - tsum, mrun = mbase + mincl - msum;
+    for (uint32_t k = 0; k < kPer; k++) { s_rank[tid * kPer + k] = run; run += c[k]; s_mrank[tid * kPer + k] = (uint16_t)mrun; mrun += cm[k]; }
     if (tid == kBlockifyThreads - 1) s_rank[kMaskWords] = run;
     __syncthreads();
 
@@ -982,14 +997,14 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
     // before the first use.  (One byte per thread per load left the loop waiting out ~200 global
     // round trips per chunk.)  A position's block is the number of block starts at or before it.
     const uint8_t* data = in + in_off[chunk];
-    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    const uint32_t* chosen = chosen_of(links, chunk);
     const uint4* d4 = reinterpret_cast<const uint4*>(data);          // readable up to L rounded up to 16 (API contract)
     const uint32_t c1 = ci.n_blocks > 1 ? s_start[1] : 0xffffffffu, c2 = ci.n_blocks > 2 ? s_start[2] : 0xffffffffu;
     const uint32_t c3 = ci.n_blocks > 3 ? s_start[3] : 0xffffffffu, c4 = ci.n_blocks > 4 ? s_start[4] : 0xffffffffu;
     auto block_of = [&](uint32_t p) { return (uint32_t)(p >= c1) + (uint32_t)(p >= c2) + (uint32_t)(p >= c3) + (uint32_t)(p >= c4); };
     const uint32_t ngroups = (L + 15u) >> 4;
     for (uint32_t g0 = tid; g0 < ngroups; g0 += 4 * kBlockifyThreads) {
-        uint4 bytes[4]; uint32_t lits[4], mats[4], sel[4];
+        uint4 bytes[4]; uint32_t lits[4], mats[4]; uint64_t mword[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             const uint32_t g = g0 + u * kBlockifyThreads;
@@ -997,8 +1012,8 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
             const uint32_t wi = in ? g >> 2 : 0u, sh = (g & 3u) * 16u;
             bytes[u] = in ? d4[g] : make_uint4(0, 0, 0, 0);
             const uint32_t sy = in ? (uint32_t)(s_sym[wi] >> sh) & 0xffffu : 0u;
-            const uint32_t mt = in ? (uint32_t)(gmst[wi] >> sh) & 0xffffu : 0u;
-            sel[u] = in ? (uint32_t)(gm32[wi] >> sh) & 0xffffu : 0u;
+            mword[u] = in ? gmst[wi] : 0ull;
+            const uint32_t mt = (uint32_t)(mword[u] >> sh) & 0xffffu;
             mats[u] = sy & mt; lits[u] = sy & ~mt;
         }
 #pragma unroll
@@ -1021,16 +1036,19 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
                 }
             }
             uint32_t mm = mats[u];
-            while (mm) {                                 // match records, four loads in flight
-                uint32_t q[4]; uint2 e2[4];
+            while (mm) {                                 // chosen records, four loads in flight
+                uint32_t q[4], e4[4];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) { q[k] = mm ? pg + (uint32_t)__builtin_ctz(mm) : 0xffffffffu; mm &= mm - 1u; }
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) e2[k] = ent[q[k] != 0xffffffffu ? q[k] : pg];
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t qq = q[k] != 0xffffffffu ? q[k] : pg;
+                    e4[k] = chosen[(uint32_t)s_mrank[qq >> 6] + (uint32_t)__popcll(mword[u] & ((1ull << (qq & 63u)) - 1ull))];
+                }
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     if (q[k] == 0xffffffffu) continue;
-                    const uint32_t e = ((sel[u] >> (q[k] & 15u)) & 1u) ? e2[k].y : e2[k].x;
+                    const uint32_t e = e4[k];
                     const uint32_t bk = b_lo == b_hi ? b_lo : block_of(q[k]);
                     atomicAdd(&s_hist[bk][257u + length_code(entry_len(e) - kMinMatch)], 1u);
                     atomicAdd(&s_hist[bk][kLCodes + dist_code(entry_dist(e) - 1u)], 1u);
@@ -1897,10 +1915,10 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst, a.m32,
-                       a.info, a.blocks);
+                       a.info, a.blocks, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(plan_probe_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes);
     hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + 63u) / 64u), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
