@@ -69,7 +69,7 @@ struct DeflateArgs {
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
-    BlockProbe* probes;        // kMaxBlocks per chunk; aliases `links`, which is dead once lz_match has run
+    BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
     // The chosen record of every match symbol, compact and in stream order (lz_parse -> blockify, encode): a chunk's
     // array also lives in its dead `links` space, kChosenOffset bytes in (behind the probes), < 21 846 entries.
 };

@@ -32,6 +32,14 @@ namespace zwz {
 static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
+// a chunk's dead link space: its kMaxBlocks BlockProbes first, its chosen records from kChosenOffset on
+static __device__ __forceinline__ BlockProbe* probe_of(BlockProbe* probes_base, uint32_t g) {
+    uint8_t* region = reinterpret_cast<uint8_t*>(probes_base) + (size_t)(g / kMaxBlocks) * (kLinkStride * sizeof(uint16_t));
+    return reinterpret_cast<BlockProbe*>(region) + g % kMaxBlocks;
+}
+static __device__ __forceinline__ const BlockProbe* probe_of(const BlockProbe* probes_base, uint32_t g) {
+    return probe_of(const_cast<BlockProbe*>(probes_base), g);
+}
 static __device__ __forceinline__ uint32_t* chosen_of(const uint16_t* links, uint32_t chunk) {
     return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(links + (size_t)chunk * kLinkStride)) + kChosenOffset);
 }
@@ -1146,7 +1154,7 @@ __global__ __launch_bounds__(64) void plan_probe_kernel(const ChunkInfo* __restr
     __shared__ uint16_t lf[kLCodes + 2], df[kDCodes + 2];
     __shared__ __attribute__((aligned(16))) uint32_t keys[kSortKeys];
     const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
-    BlockProbe* pb = probes + blockIdx.x;
+    BlockProbe* pb = probe_of(probes, blockIdx.x);
     const BlockInfo* bi = blocks + blockIdx.x;
     if (b >= info[chunk].n_blocks) { if (threadIdx.x == 0) pb->state = kProbeNone; return; }
     const uint32_t stored_len = bi->end - bi->start;
@@ -1206,14 +1214,15 @@ __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ 
     __shared__ uint32_t arr[64 * kCostLaneWords];
     const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u;
     const uint32_t g = g0 + lane;
-    const bool live = g < n_blocks_total && probes[g].state == kProbeOpen;
+    BlockProbe* mine = probe_of(probes, g < n_blocks_total ? g : 0u);
+    const bool live = g < n_blocks_total && mine->state == kProbeOpen;
     uint32_t m_l = 0, m_d = 0;
-    if (live) { m_l = probes[g].m_l; m_d = probes[g].m_d; }
+    if (live) { m_l = mine->m_l; m_d = mine->m_d; }
     // stage the sorted counts of every probed block of this wave: lane-private rows, coalesced copy
     for (uint32_t j = 0; j < 64; j++) {
         const uint32_t ml = __shfl(m_l, j), md = __shfl(m_d, j);
         if (ml == 0) continue;                           // not a block (a block counts at least its end-of-block symbol)
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(probes[g0 + j].lit);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(probe_of(probes, g0 + j)->lit);
         uint32_t* dst = arr + j * kCostLaneWords;
         for (uint32_t w = lane; w < (ml + 1u) / 2u; w += 64) dst[w] = src[w];
         if (lane < (md + 1u) / 2u) dst[144 + lane] = src[144 + lane];
@@ -1225,9 +1234,9 @@ __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ 
     const uint32_t hl = lane_huffman_cost(row, m_l, max_l);
     const uint32_t hd = lane_huffman_cost(row + 288, m_d, max_d);
     if (live) {
-        const StoredProbe pr{probes[g].static_len, probes[g].extra_bits, probes[g].used};
-        const uint32_t t = shortcut_type(pr, hl, hd, probes[g].stored_len, probes[g].stored_ok != 0);
-        if (t != kShortNone) probes[g].state = t == kShortStored ? kProbeStored : kProbeStatic;
+        const StoredProbe pr{mine->static_len, mine->extra_bits, mine->used};
+        const uint32_t t = shortcut_type(pr, hl, hd, mine->stored_len, mine->stored_ok != 0);
+        if (t != kShortNone) mine->state = t == kShortStored ? kProbeStored : kProbeStatic;
     }
 }
 
@@ -1242,14 +1251,15 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
     BlockOut* bo = plans + (size_t)chunk * kMaxBlocks + b;
     const uint32_t last = b + 1 == info[chunk].n_blocks;
-    const uint32_t settled = probes[blockIdx.x].state;
+    const BlockProbe* mine = probe_of(probes, blockIdx.x);
+    const uint32_t settled = mine->state;
     if (settled == kProbeStored) {                      // codes are never read for stored blocks
         if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
         return;
     }
     if (settled == kProbeStatic) {                      // the static codes, written out so the encoder needs no special case
         if (threadIdx.x == 0) {
-            bo->type = kStatic; bo->hdr_bits = 3; bo->body_bits = probes[blockIdx.x].static_len; bo->hdr[0] = (1u << 1) + last;
+            bo->type = kStatic; bo->hdr_bits = 3; bo->body_bits = mine->static_len; bo->hdr[0] = (1u << 1) + last;
             bo->eob_len = static_lit_len(256); bo->eob_code = static_lit_code(256);
         }
         for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) { bo->llen[i] = (uint8_t)static_lit_len(i); bo->lcode[i] = (uint16_t)static_lit_code(i); }
@@ -1384,7 +1394,8 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
                                                                 const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
                                                                 const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
-                                                                uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len) {
+                                                                uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
+                                                                const uint16_t* __restrict__ links) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
     uint64_t* s_sym = reinterpret_cast<uint64_t*>(smem + kOutWords * 4);          // kMaskWords
@@ -1394,7 +1405,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
     uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
     __shared__ EncBlock s_blk[kMaxBlocks];
-    __shared__ uint32_t s_wsum[kEncodeThreads / 64];
+    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_msum[kEncodeThreads / 64];
     __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
     __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
 
@@ -1405,10 +1416,9 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks;
     const BlockOut* bo = plans + (size_t)chunk * kMaxBlocks;
     const uint8_t* data = in + in_off[chunk];
-    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    const uint32_t* chosen = chosen_of(links, chunk);
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
-    const uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
 
     {   // wave-uniform: are all blocks stored?
         bool all_stored = ci.n_blocks > 0;
@@ -1419,17 +1429,21 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         }
     }
     for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
-    // symbol ranks again (cheaper to recompute than to round-trip through HBM)
+    // symbol ranks again (cheaper to recompute than to round-trip through HBM), and match ranks: thread t holds mask
+    // word t, wave w's words are exactly its 4096-position segment below
+    const uint64_t mst_l = tid < nwords ? gmst[tid] : 0ull;   // kEncodeThreads == kMaskWords
+    uint32_t mprefix;                                         // matches before this thread's word = its first index into `chosen`
     {
-        uint64_t w = tid < nwords ? gsym[tid] : 0ull;   // kEncodeThreads == kMaskWords
+        uint64_t w = tid < nwords ? gsym[tid] : 0ull;
         s_sym[tid] = w;
-        uint32_t cnt = (uint32_t)__popcll(w), incl = cnt;
-        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d); if (lane_id() >= d) incl += v; }
-        if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+        const uint32_t cnt = (uint32_t)__popcll(w), incl = wave_scan_incl(cnt);
+        const uint32_t mcnt = (uint32_t)__popcll(mst_l), mincl = wave_scan_incl(mcnt);
+        if (lane_id() == 63) { s_wsum[tid >> 6] = incl; s_msum[tid >> 6] = mincl; }
         __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t i = 0; i < (tid >> 6); i++) wbase += s_wsum[i];
+        uint32_t wbase = 0, mbase = 0;
+        for (uint32_t i = 0; i < (tid >> 6); i++) { wbase += s_wsum[i]; mbase += s_msum[i]; }
         s_rank[tid] = (uint16_t)(wbase + incl - cnt);
+        mprefix = mbase + mincl - mcnt;
     }
     for (uint32_t b = 0; b < ci.n_blocks; b++) {
         if (bo[b].type == kStored) continue;   // stored blocks carry no codes (plan may not have built any)
@@ -1494,12 +1508,10 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         // or before it (holds for covered positions too: a block ends where its last symbol ends)
         const uint32_t b1 = ci.n_blocks > 1 ? s_blk[1].start : 0xffffffffu, b2 = ci.n_blocks > 2 ? s_blk[2].start : 0xffffffffu;
         const uint32_t b3 = ci.n_blocks > 3 ? s_blk[3].start : 0xffffffffu, b4 = ci.n_blocks > 4 ? s_blk[4].start : 0xffffffffu;
-        // The segment's 64 words of the match / selector masks sit one per lane and are handed out by
-        // v_readlane; each trip's byte and match record are fetched one trip ahead (the loop was
-        // bound by a global-load round trip per trip).
-        const uint32_t w0 = seg >> 6;
-        const uint64_t mst_l = (w0 + lane < nwords) ? gmst[w0 + lane] : 0ull;
-        const uint64_t m32_l = (w0 + lane < nwords) ? gm32[w0 + lane] : 0ull;
+        // The segment's 64 words of the match mask (and the match count in front of each) sit one per lane and are
+        // handed out by v_readlane; each trip's byte and chosen record are fetched one trip ahead.  The records come
+        // from lz_parse's compact array: read from the position-indexed one, every 64-byte line of its 512 KB
+        // held a match start and both passes fetched all of it (~50 GB a pass on text).
         auto word_of = [&](uint64_t v, uint32_t it) -> uint64_t {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, it);          // the builtin returns int:
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), it);  // widen only after the cast
@@ -1508,11 +1520,12 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
         auto fetch = [&](uint32_t it, uint32_t& byte, uint32_t& e) {   // trip `it` of this wave's segment
             byte = 0; e = 0;
             if (it >= 64u) return;                                     // wave-uniform
-            const uint64_t mw = word_of(mst_l, it), sw = word_of(m32_l, it);   // readlane outside divergent code
+            const uint64_t mw = word_of(mst_l, it);                    // readlane outside divergent code
+            const uint32_t mfirst = (uint32_t)__builtin_amdgcn_readlane((int)mprefix, it);
             const uint32_t p = seg + (it << 6) + lane;
             if (p < seg_end) {
                 byte = data[p];
-                if ((mw >> lane) & 1ull) { const uint2 e2 = ent[p]; e = ((sw >> lane) & 1ull) ? e2.y : e2.x; }
+                if ((mw >> lane) & 1ull) e = chosen[mfirst + (uint32_t)__popcll(mw & lanes_below())];   // dense: 4 bytes per match
             }
         };
         auto block_of = [&](uint32_t p) { return (uint32_t)(p >= b1) + (uint32_t)(p >= b2) + (uint32_t)(p >= b3) + (uint32_t)(p >= b4); };
@@ -1925,7 +1938,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
-                       a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len);
+                       a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
     return hipGetLastError();
 }
