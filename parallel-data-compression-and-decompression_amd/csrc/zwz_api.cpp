@@ -251,7 +251,6 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.has128 = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.sym = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
-    a.m32 = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
     a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));

@@ -65,7 +65,7 @@ struct DeflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned
     uint8_t* out; uint64_t out_stride; uint32_t* out_len;                            // out_stride % 4 == 0, >= 65536
     // workspace (sized for n chunks)
-    uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst; uint64_t* m32;
+    uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
@@ -80,7 +80,7 @@ struct InflateArgs {
 };
 
 constexpr size_t kWorkspaceBytesPerChunk =
-    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 4 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) +
+    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
 
 hipError_t configure_kernels();

@@ -775,7 +775,7 @@ struct ParseWaveMem {
 __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n,
                                                                 const uint2* __restrict__ entries, const uint64_t* __restrict__ has128,
                                                                 uint64_t* __restrict__ sym, uint64_t* __restrict__ mst,
-                                                                uint64_t* __restrict__ m32, ChunkInfo* __restrict__ info, uint16_t* __restrict__ links) {
+                                                                ChunkInfo* __restrict__ info, uint16_t* __restrict__ links) {
     __shared__ ParseWaveMem s_mem[kParseThreads / 64];
     const uint32_t chunk = blockIdx.x * (kParseThreads / 64) + (threadIdx.x >> 6);
     if (chunk >= n) return;
@@ -785,7 +785,6 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
-    uint64_t* gm32 = m32 + (size_t)chunk * kMaskWords;
     const uint32_t L = in_len[chunk];
     const uint32_t nwords = (L + 63) >> 6;
 
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
                 const uint64_t zeros = __ballot(word == 0 && ((w + 1u) << 6) <= L);
                 const uint32_t run = zeros == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~zeros);
                 if (run >= 2u) {
-                    if (lane < run) { gsym[w] = ~0ull; gmst[w] = 0; gm32[w] = 0; }
+                    if (lane < run) { gsym[w] = ~0ull; gmst[w] = 0; }
                     n_sym += 64u * run;
                     const uint32_t nb = blk + run;
                     if (lane == 0) { m.ring_r[slot] = 0; if ((nb << 6) < L) m.ring_r[2 * (nb & 7u)] |= 1u; }
@@ -860,7 +859,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
                 const uint64_t vm = __ballot(valid);
                 n_sym += (uint32_t)__popcll(vm);
                 if (lane == 0) {
-                    gsym[blk] = vm; gmst[blk] = 0; gm32[blk] = 0;
+                    gsym[blk] = vm; gmst[blk] = 0;
                     m.ring_r[slot] = 0;
                     if (base + 64u < L) m.ring_r[2 * ((blk + 1u) & 7u)] |= 1u;
                 }
@@ -918,7 +917,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         carry_open = (uint32_t)(cover >> 63);
         const uint64_t sym_w = ~cover & validm;
         n_sym += (uint32_t)__popcll(sym_w);
-        if (lane == 0) { gsym[blk] = sym_w; gmst[blk] = M; gm32[blk] = M32; }
+        if (lane == 0) { gsym[blk] = sym_w; gmst[blk] = M; }
         if (M) {                                     // this block's match starts are final: their records go out, selected and compact
             if ((M >> lane) & 1ull) {
                 const uint2 e = m.win[q & 127u];
@@ -947,7 +946,7 @@ static __device__ __forceinline__ uint32_t select_bit(uint64_t w, uint32_t k) { 
 __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                    const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                    const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
-                                                                   const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
+                                                                   const ChunkInfo* __restrict__ info,
                                                                    BlockInfo* __restrict__ blocks, const uint16_t* __restrict__ links) {
     __shared__ uint64_t s_sym[kMaskWords];
     __shared__ uint32_t s_rank[kMaskWords + 1];   // symbols before word w
@@ -1392,7 +1391,7 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
 __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
-                                                                const uint64_t* __restrict__ m32, const ChunkInfo* __restrict__ info,
+                                                                const ChunkInfo* __restrict__ info,
                                                                 const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
                                                                 uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
                                                                 const uint16_t* __restrict__ links) {
@@ -1928,9 +1927,9 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.m32, a.info, a.links);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
-    hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst, a.m32,
+    hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst,
                        a.info, a.blocks, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(plan_probe_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes);
@@ -1938,7 +1937,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
-                       a.mst, a.m32, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links);
+                       a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
     return hipGetLastError();
 }
