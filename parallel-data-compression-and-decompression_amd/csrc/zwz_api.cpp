@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -68,6 +69,13 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
     c->max_batch = max_batch ? max_batch : 8192u;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = configure_kernels();
+    if (e == hipSuccess) {
+        // lz_links flavour: the one-exchange-per-step kernel where the device's LDS exchange behaves as it needs (checked
+        // here, once per context), the read/write/read-back kernel otherwise or when ZWZ_LINKS=pair asks for it
+        const char* want = getenv("ZWZ_LINKS");
+        if (want && !strcmp(want, "pair")) c->links_xchg = false;
+        else e = probe_exchange_order(c->stream, &c->links_xchg);
+    }
     for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
     if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create"); zwz_ctx_destroy(c); return rc; }
@@ -253,6 +261,7 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
     a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+    a.links_xchg = c->links_xchg ? 1u : 0u;
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
     a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));

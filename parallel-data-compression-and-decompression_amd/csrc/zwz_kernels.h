@@ -12,6 +12,8 @@ namespace zwz {
 constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
 constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
 constexpr uint32_t kLinksThreads = 128;                            // one inserter wave + one feeder wave per chunk
+constexpr uint32_t kLinksXThreads = 320;                           // exchange flavour: one inserter wave + four feeder waves
+constexpr uint32_t kLinksXLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // exchange flavour: 32-bit buckets, 32-bit buffer entries
 constexpr uint32_t kLinksLdsBytes = 65536 + 16 + 2 * 2048 * 2 + 256;  // head table + dummy slot + two hash/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
@@ -67,6 +69,7 @@ struct DeflateArgs {
     // workspace (sized for n chunks)
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
+    uint32_t links_xchg;       // lz_links flavour: 1 = one exchange per step on 32-bit buckets (ZWZ_LINKS, see zwz_api.cpp)
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
@@ -84,6 +87,7 @@ constexpr size_t kWorkspaceBytesPerChunk =
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
 
 hipError_t configure_kernels();
+hipError_t probe_exchange_order(hipStream_t s, bool* holds);   // see exchange_order_probe_kernel
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* stage_events);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,

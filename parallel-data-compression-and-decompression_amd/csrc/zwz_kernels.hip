@@ -86,16 +86,26 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // by the lane whose store lost (insert_block); anything more -- several losers, a later step holding the
 // same hash -- drains and goes through the general repair in C++, and blocks in which that keeps
 // happening (text) run a plain one-step-at-a-time loop instead (insert_block_dense).
+//
+// That is the "pair" flavour (lz_links_kernel<false>), kept as the fallback.  The flavour a context normally runs
+// (lz_links_kernel<true>, chosen in zwz_ctx_create after exchange_order_probe_kernel has passed on the device) needs none of
+// the collision machinery: with 32-bit buckets one ds_wrxchg_rtn_b32 per step both stores the positions and returns each
+// lane's predecessor, same-address lanes being served in ascending lane order -- zlib's insert order.  Its cost is
+// data-independent, 64 cycles a step (the LDS retires an exchange one lane a cycle), the same on text and on random bytes:
+// 5.4 ms per 50 000 chunks against 5.8 / 35.6 ms.  The 128 KiB table leaves room for one chunk per CU, so the feeder's work
+// is spread over four waves (8 positions a lane a block) to keep it off the critical path.
 constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
 constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (see below: any bucket will do)
 
-__global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+template <bool kXchg>
+__global__ __launch_bounds__(kXchg ? kLinksXThreads : kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
                                                                  uint32_t* __restrict__ link_stat) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
-    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries + the dummy slot
-    uint16_t* hbuf = head + 32768 + 8;                                       // 2 x kLinksBlock: hashes in, links out
+    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries (kXchg: 32-bit ones) + 16 spare bytes
+    constexpr uint32_t kHeadBytes = kXchg ? 131072u : 65536u;
+    uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock: hashes in, links out
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t L = in_len[chunk];
     if (L == 0) { if (tid == 0) link_stat[chunk] = 0; return; }
@@ -105,49 +115,76 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
 
     uint4* h4 = reinterpret_cast<uint4*>(head);
-    for (uint32_t i = tid; i < (65536u + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    constexpr uint32_t kThreads = kXchg ? kLinksXThreads : kLinksThreads;
+    for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    if (kXchg && tid == 0) link_stat[chunk] = 0;       // the feeder waves add their counts at the end
 
     // ---- feeder
     // the feeder keeps the next block's input in registers, loaded one hand-over ahead: a block's ~2 us of HBM
     // latency is then hidden behind the previous block's work (issued and consumed in the same hand-over it was the
     // critical path of the whole kernel: 5 k cycles per block against the inserter's 2.5 k)
-    uint4 in_a = make_uint4(0, 0, 0, 0), in_b = in_a; uint32_t in_c = 0;
-    auto load_block = [&](uint32_t k) {            // input bytes [2048 k + 32 lane, + 36) -> in_a, in_b, in_c
-        const uint32_t o = k * kLinksBlock + lane * 32u;
+    constexpr uint32_t kFeeders = kXchg ? (kLinksXThreads / 64u - 1u) : 1u;    // feeder waves, each with its own share of every block
+    constexpr uint32_t kPer = 32u / kFeeders;         // positions per feeder lane per block
+    constexpr uint32_t kW = kPer / 4u;
+    uint32_t in_w[kW + 1];
+#pragma unroll
+    for (uint32_t j = 0; j <= kW; j++) in_w[j] = 0;
+    const uint32_t fpos = (wave - 1u) * (kLinksBlock / kFeeders) + lane * kPer;   // this lane's share within a block (feeder waves)
+    auto load_block = [&](uint32_t k) {            // input bytes [2048 k + fpos, + kPer + 4) -> in_w
+        const uint32_t o = k * kLinksBlock + fpos;
         const uint4* g = reinterpret_cast<const uint4*>(data + o);
-        in_a = make_uint4(0, 0, 0, 0); in_b = in_a; in_c = 0;
-        if (o + 16u <= Lr) in_a = g[0];
-        if (o + 32u <= Lr) in_b = g[1];
-        if (o + 36u <= Lr) in_c = reinterpret_cast<const uint32_t*>(data + o)[8];
+        if (kW == 2u) {
+            uint2 v = make_uint2(0, 0);
+            if (o + 8u <= Lr) v = *reinterpret_cast<const uint2*>(data + o);
+            in_w[0] = v.x; in_w[1] = v.y;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kW / 4u; j++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o + 16u * j + 16u <= Lr) v = g[j];
+            in_w[4 * j] = v.x; in_w[4 * j + 1] = v.y; in_w[4 * j + 2] = v.z; in_w[4 * j + 3] = v.w;
+        }
+        in_w[kW] = 0;
+        if (o + kPer + 4u <= Lr) in_w[kW] = reinterpret_cast<const uint32_t*>(data + o)[kW];
     };
     typedef __attribute__((address_space(3))) uint8_t* lds_byte_ptr;
     const uint32_t head_base = (uint32_t)(uintptr_t)(lds_byte_ptr) reinterpret_cast<uint8_t*>(head);   // 0: this kernel has no static LDS
-    auto hash_block = [&](uint32_t k) {            // hashes of positions [2048 k, 2048 k + 2048) from the loaded input: 32 per lane
-        const uint32_t o = k * kLinksBlock + lane * 32u;
-        const uint32_t w[9] = {in_a.x, in_a.y, in_a.z, in_a.w, in_b.x, in_b.y, in_b.z, in_b.w, in_c};
-        const uint32_t n_ok = L >= o + kMinMatch ? min(32u, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
-        uint32_t packed[16];
+    auto hash_block = [&](uint32_t k) {            // bucket addresses of positions [2048 k + fpos, + kPer) from the loaded input
+        const uint32_t o = k * kLinksBlock + fpos;
+        const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
+        uint32_t e[kPer];
 #pragma unroll
-        for (uint32_t i = 0; i < 32; i++) {
-            const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3u) : w[i >> 2];
+        for (uint32_t i = 0; i < kPer; i++) {
+            const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(in_w[(i >> 2) + 1], in_w[i >> 2], i & 3u) : in_w[i >> 2];
             uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
             if (i >= n_ok) h = kLinksNoHash;
-            h = 2u * h + head_base;                    // the bucket's LDS byte address (fits 16 bits: the head table starts at LDS address 0)
-            if (i & 1u) packed[i >> 1] |= h << 16; else packed[i >> 1] = h;
+            e[i] = (kXchg ? 4u : 2u) * h + head_base;  // the bucket's LDS byte address (2-byte buckets: fits 16 bits, the table starts at LDS address 0)
         }
-        uint4* dst = reinterpret_cast<uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
+        if (kXchg) {                                   // 32-bit entries
+            uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(hbuf) + (k & 1u) * kLinksBlock + fpos);
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) dst[j] = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
+            for (uint32_t j = 0; j < kPer / 4u; j++) dst[j] = make_uint4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+        } else {
+            uint4* dst = reinterpret_cast<uint4*>(hbuf + (k & 1u) * kLinksBlock + fpos);
+#pragma unroll
+            for (uint32_t j = 0; j < kPer / 8u; j++)
+                dst[j] = make_uint4(e[8 * j] | e[8 * j + 1] << 16, e[8 * j + 2] | e[8 * j + 3] << 16, e[8 * j + 4] | e[8 * j + 5] << 16, e[8 * j + 6] | e[8 * j + 7] << 16);
+        }
     };
     uint32_t linked = 0;                               // feeder: positions of this lane with a chain predecessor
     auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
-        const uint32_t o = k * kLinksBlock + lane * 32u;
-        const uint4* src = reinterpret_cast<const uint4*>(hbuf + (k & 1u) * kLinksBlock + lane * 32u);
+        const uint32_t o = k * kLinksBlock + fpos;
+        const uint4* src = reinterpret_cast<const uint4*>(hbuf + (k & 1u) * kLinksBlock + fpos);
+        const uint4* s32 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(hbuf) + (k & 1u) * kLinksBlock + fpos);
         uint4* dst = reinterpret_cast<uint4*>(lk + o);
-        const uint32_t n_ok = L >= o + kMinMatch ? min(32u, L - o - (kMinMatch - 1u)) : 0u;
+        const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            uint4 v = src[j];
+        for (uint32_t j = 0; j < kPer / 8u; j++) {
+            uint4 v;
+            if (kXchg) {                           // 32-bit slots, the link in each one's low half
+                const uint4 lo = s32[2 * j], hi = s32[2 * j + 1];
+                v = make_uint4((lo.x & 0xffffu) | lo.y << 16, (lo.z & 0xffffu) | lo.w << 16, (hi.x & 0xffffu) | hi.y << 16, (hi.z & 0xffffu) | hi.w << 16);
+            } else v = src[j];
             if (n_ok < 8u * j + 8u) {              // rare: the chunk's last positions
                 uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -166,7 +203,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     // ---- inserter
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
     const uint32_t head_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(head));   // LDS byte addresses
-    const uint32_t hbuf_a = head_a + 2u * (32768u + 8u);
+    const uint32_t hbuf_a = head_a + kHeadBytes + 16u;
     struct Step { uint32_t p16, prev, rb; };           // position, head read, read-back of one 64-position step
     auto lds_u16 = [&](uint32_t addr) -> uint32_t {    // complete on return
         uint32_t v;
@@ -398,15 +435,78 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         slow_exits = collided;                            // stay dense while most steps collide
     };
 
+    // ---- inserter, exchange flavour (kXchg): 32-bit buckets and ONE operation per step.  ds_wrxchg_rtn_b32 hands every lane
+    // the value the nearest lower lane with the same address wrote (the old bucket value to the lowest) and leaves the highest
+    // lane's value behind -- measured on gfx950 (tools/exp/xchg_order.hip), and probed again at context creation -- which is
+    // exactly zlib's insert-in-position-order: no read-back, no collisions to repair, whatever the data.  The price is a
+    // 128 KiB table: one chunk per CU instead of two.
+    auto insert_block_x = [&](uint32_t k) {
+        const uint32_t first = k * kLinksBlock;
+        const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);      // >= 1
+        uint32_t base = hbuf_a + 4u * ((k & 1u) * kLinksBlock + lane);                    // this lane's buffer entry of step s
+        uint32_t p0 = first + lane;
+        auto step_now = [&](uint32_t slot, uint32_t p) {                                  // one step, start to finish
+            uint32_t a, prev;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(slot) : "memory");
+            asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(prev) : "v"(a), "v"(p) : "memory");
+            asm volatile("ds_write_b32 %0, %1" :: "v"(slot), "v"(prev) : "memory");
+        };
+        uint32_t s = 0;
+        if (n_steps >= 6u) {
+            // steps s, s+1 issued; bucket addresses of s+2, s+3 at hand; then three steps a trip: read the address of step t+2,
+            // exchange for step t, write the link of step t-2 into its slot.  Three LDS operations a step, in order, so "the
+            // exchange of t-2 is back" (and with it the address of t, which is older) is lgkmcnt(5).  Deeper pipelining buys
+            // nothing: the exchange itself retires one lane a cycle, 64 cycles a step, and that is the kernel's time.
+            uint32_t g0, g1, g2, q0, q1, q2, p1 = p0 + 64u, p2 = p0 + 128u, t0, t1;
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
+                         "s_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1), "=&v"(g2), "=&v"(g0) : "v"(base) : "memory");
+            asm volatile("ds_wrxchg_rtn_b32 %0, %2, %4\n\tds_wrxchg_rtn_b32 %1, %3, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1) : "v"(t0), "v"(t1), "v"(p0), "v"(p1) : "memory");
+            uint32_t left = __builtin_amdgcn_readfirstlane(n_steps - 2u);
+            g1 = 0; q2 = 0;
+#define ZWZ_XSTEP(HN, HN_OFF, HC, QC, PPOS, QR, RPOS, ROFF)                                          \
+                "ds_read_b32 %[" HN "], %[base] offset:" HN_OFF "\n\t"                                 \
+                "s_waitcnt lgkmcnt(5)\n\t"                                                           \
+                "ds_wrxchg_rtn_b32 %[" QC "], %[" HC "], %[" PPOS "]\n\t"                            \
+                "ds_write_b32 %[base], %[" QR "] offset:" ROFF "\n\t"                                \
+                "v_add_u32 %[" RPOS "], 0xc0, %[" RPOS "]\n\t"
+            asm volatile(
+                "1:\n\t"
+                ZWZ_XSTEP("g1", "1024", "g2", "q2", "p2", "q0", "p0", "0")       /* issue s+2, retire s */
+                ZWZ_XSTEP("g2", "1280", "g0", "q0", "p0", "q1", "p1", "256")     /* issue s+3, retire s+1 */
+                ZWZ_XSTEP("g0", "1536", "g1", "q1", "p1", "q2", "p2", "512")     /* issue s+4, retire s+2 */
+                "v_add_u32 %[base], 0x300, %[base]\n\t"
+                "s_sub_u32 %[left], %[left], 3\n\t"
+                "s_cmp_gt_u32 %[left], 2\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2),
+                  [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [base] "+v"(base), [left] "+s"(left)
+                :
+                : "scc", "memory");
+#undef ZWZ_XSTEP
+            // steps s, s+1 (sets 0, 1) are complete and not yet written out
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256" :: "v"(base), "v"(q0), "v"(q1) : "memory");
+            s = n_steps - left;                                                           // first step not issued yet
+            base += 512u; p0 = p2;                                                        // p2 = position of step s (two past set 0's)
+        }
+        for (; s < n_steps; s++) { step_now(base, p0); base += 256u; p0 += 64u; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the feeder reads these links right after the barrier
+    };
+
     __syncthreads();
-    if (wave == 1) {
+    if (wave >= 1) {
         load_block(0);
         hash_block(0);
         if (n_blocks > 1) load_block(1);
     }
     __syncthreads();
     for (uint32_t k = 0; k < n_blocks; k++) {
-        if (wave == 0) { if (slow_exits >= 6u) insert_block_dense(k); else insert_block(k); }
+        if (wave == 0) {
+            if (kXchg) insert_block_x(k);
+            else if (slow_exits >= 6u) insert_block_dense(k);
+            else insert_block(k);
+        }
         else {
             if (k >= 1) flush_block(k - 1);
             if (k + 1 < n_blocks) {
@@ -414,12 +514,16 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 if (k + 2 < n_blocks) load_block(k + 2);
             }
         }
-        __syncthreads();
+        // the hand-over concerns LDS only: __syncthreads() would also drain the feeder's input loads and link stores,
+        // putting a block's HBM latency back on the critical path of every hand-over
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (wave == 1) {
+    if (wave >= 1) {
         flush_block(n_blocks - 1);
         for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
-        if (lane == 0) link_stat[chunk] = linked;       // lz_match picks its work order by it
+        if (lane == 0) {                                // lz_match picks its work order by it
+            if (kFeeders > 1) atomicAdd(&link_stat[chunk], linked); else link_stat[chunk] = linked;
+        }
     }
 }
 
@@ -1912,8 +2016,55 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
 // launchers
 #define ZWZ_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
+// The exchange flavour of lz_links stands on a property of ds_wrxchg_rtn_b32 the ISA manual does not spell out: lanes of one
+// instruction that name the same address are served in ascending lane order (each gets what the nearest lower such lane wrote,
+// the lowest gets the old value, the highest lane's value stays).  One wave checks it on this device, over address patterns
+// from all-equal to all-distinct; a context whose device fails the check uses the read/write/read-back flavour instead.
+__global__ __launch_bounds__(64) void exchange_order_probe_kernel(uint32_t* __restrict__ violations) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t addr[64];
+    const uint32_t lane = threadIdx.x;
+    uint32_t bad = 0, rng = 0x9e3779b9u * (lane + 1u);
+    for (uint32_t r = 0; r < 512; r++) {
+        for (uint32_t i = lane; i < 256; i += 64) tab[i] = 0xdead0000u + i;
+        rng = rng * 1664525u + 1013904223u;
+        const uint32_t spread = 1u << (2u * (r % 5u));                           // 1, 4, 16, 64, 256 buckets
+        const uint32_t a = (rng >> 12) & (spread - 1u);
+        addr[lane] = a;
+        __syncthreads();
+        typedef __attribute__((address_space(3))) uint32_t* lds_word_ptr;
+        const uint32_t la = (uint32_t)(uintptr_t)(lds_word_ptr)&tab[a];
+        uint32_t old;
+        asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(la), "v"(0x1000u + lane) : "memory");
+        __syncthreads();
+        uint32_t want = 0xdead0000u + a, last = lane;
+        for (uint32_t j = 0; j < 64; j++) {
+            if (addr[j] != a) continue;
+            if (j < lane) want = 0x1000u + j;
+            if (j > lane) last = j;
+        }
+        bad += (uint32_t)(old != want) + (uint32_t)(tab[a] != 0x1000u + last);
+        __syncthreads();
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
+    uint32_t* d = nullptr;
+    uint32_t h = 1;
+    ZWZ_TRY(hipMalloc(&d, sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(exchange_order_probe_kernel, dim3(1), dim3(64), 0, s, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    *holds = e == hipSuccess && h == 0;
+    return e;
+}
+
 hipError_t configure_kernels() {
-    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksXLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
     return hipSuccess;
@@ -1922,7 +2073,8 @@ hipError_t configure_kernels() {
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
+    if (a.links_xchg) hipLaunchKernelGGL(lz_links_kernel<true>, dim3(a.n), dim3(kLinksXThreads), kLinksXLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
+    else hipLaunchKernelGGL(lz_links_kernel<false>, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat);
