@@ -31,6 +31,10 @@ namespace zwz {
 
 static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
+// set bits of a wave mask below this lane (v_mbcnt pair: two instructions against four for popc(m & lanes_below()))
+static __device__ __forceinline__ uint32_t rank_in(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // a chunk's dead link space: its kMaxBlocks BlockProbes first, its chosen records from kChosenOffset on
 static __device__ __forceinline__ BlockProbe* probe_of(BlockProbe* probes_base, uint32_t g) {
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         // positions of one bucket at a time (~0.58 utilisation, half the trips).  Chunks with sparse
         // chains (lz_links' count, above) take the screening pass instead.
         const uint32_t npos = te - ts;
-        const uint32_t wave = tid >> 6, lane = lane_id();
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = lane_id();   // (the compiler does not see tid >> 6 as wave-uniform)
         auto key_of = [&](uint32_t p) -> uint32_t {
             if (p >= te || p + kMinMatch > L) return 7u;
             const uint32_t l1 = slink[p - org];
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 const bool in = q < npos;
                 uint32_t rank = 0;
 #pragma unroll
-                for (uint32_t b = 0; b < 8u; b++) { const uint64_t mk = __ballot(in && key == b); if (key == b) rank = (uint32_t)__popcll(mk & lanes_below()); }
+                for (uint32_t b = 0; b < 8u; b++) { const uint64_t mk = __ballot(in && key == b); if (key == b) rank = rank_in(mk); }
                 if (in) perm[(uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank] = (uint16_t)q;
             }
             __syncthreads();
@@ -792,36 +796,47 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 for (uint32_t i = lane; i - lane < nl; i += 64u) search_and_store(i < nl ? ts + (uint32_t)wl[i] : ts, i < nl);
                 nl = 0;
             };
-            for (uint32_t k0 = 0; k0 < 16u; k0 += 4u) {
+            // A lane screens four consecutive positions a trip: their links are one 8-byte read, their trigrams come out of
+            // two words.  Tests are selects on compare masks -- no flag words, no short-circuit logic (as bool tests and
+            // guarded reads this pass was mostly exec-mask bookkeeping on the CU's one scalar unit) -- and "no candidate"
+            // in all its forms (NIL, too far, no trigram, behind zlib's slid window) is one comparison: link >= floor, with
+            // floor(p) = max(1, p - MAX_DIST); a second candidate is in range iff link2 > limit(p), i.e. link2 >= floor(p + 1).
+            const uint32_t last_ok = L >= kMinMatch ? min(te, L - (kMinMatch - 1u)) : 0u;
+            const uint32_t n_ok = __builtin_amdgcn_readfirstlane(last_ok > ts ? last_ok - ts : 0u);   // the tile's positions with a trigram
+            for (uint32_t t4 = 0; t4 < 4u; t4++) {
+                const uint32_t qb = wave * 1024u + t4 * 256u;                              // wave-uniform
+                if (qb >= n_ok) break;
                 if (nl + 256u > kListCap) drain();
-                // (flags as 0/1 words and unconditional reads at clamped indices: as bool tests and guarded reads this pass was
-                // mostly exec-mask bookkeeping on the CU's one scalar unit)
-                uint32_t q[4], l1[4], scan[4], ok[4], pi[4];
+                const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = p0 - org;            // wi: window index, a multiple of 4
+                const uint2 lk2 = *reinterpret_cast<const uint2*>(slink + wi);
+                const uint32_t w0 = reinterpret_cast<const uint32_t*>(sdata + wi)[0], w1 = reinterpret_cast<const uint32_t*>(sdata + wi)[1];
+                uint32_t l1[4] = {lk2.x & 0xffffu, lk2.x >> 16, lk2.y & 0xffffu, lk2.y >> 16};
+                if (qb + 256u > n_ok) {                                                   // the chunk's last positions
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    q[u] = wave * 1024u + (k0 + u) * 64u + lane;
-                    const uint32_t p = ts + q[u];
-                    ok[u] = (uint32_t)(q[u] < npos) & (uint32_t)(p + kMinMatch <= L);
-                    pi[u] = ok[u] ? p - org : ts - org;                       // a readable stand-in for positions out of play
-                    l1[u] = slink[pi[u]];
-                    scan[u] = load_u32(sdata, pi[u]);
+                    for (uint32_t j = 0; j < 4; j++) if (q0 + j >= n_ok) l1[j] = 0;
                 }
-                uint32_t l2[4], cw[4];
+                if (ts + qb + 256u > kSlidePos) {                                         // zlib's window has slid: <= 32768 reads as NIL
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    const uint32_t p = ts + q[u];
-                    ok[u] &= (uint32_t)(l1[u] != 0) & (uint32_t)(p - l1[u] <= kMaxDist) &
-                             (((uint32_t)(p >= kSlidePos) & (uint32_t)(l1[u] <= kWSize)) ^ 1u);    // lz_search's own entry test
-                    const uint32_t li = ok[u] ? l1[u] - org : pi[u];
-                    l2[u] = slink[li];
-                    cw[u] = load_u32(sdata, li);
+                    for (uint32_t j = 0; j < 4; j++) if (p0 + j >= kSlidePos && l1[j] <= kWSize) l1[j] = 0;
+                }
+                uint32_t floor_[5], scan[4], l2[4], cw[4], okm[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++) floor_[j] = max(p0 + j, kMaxDist + 1u) - kMaxDist;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    scan[j] = (j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0) & 0xffffffu;
+                    okm[j] = l1[j] >= floor_[j] ? 0xffffffffu : 0u;
+                    const uint32_t li = okm[j] ? l1[j] - org : wi + j;                    // a readable stand-in for positions out of play
+                    l2[j] = slink[li];
+                    cw[j] = load_u32(sdata, li) & 0xffffffu;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    const uint32_t p = ts + q[u], limit = p > kMaxDist ? p - kMaxDist : 0u;
-                    const uint32_t push = ok[u] & ((uint32_t)(l2[u] > limit) | (uint32_t)(((cw[u] ^ scan[u]) & 0xffffffu) == 0u));
-                    const uint64_t m = __ballot(push != 0);
-                    if (push) wl[nl + (uint32_t)__popcll(m & lanes_below())] = (uint16_t)q[u];
+                for (uint32_t j = 0; j < 4; j++) {
+                    uint32_t v = l2[j] >= floor_[j + 1] ? scan[j] : cw[j];                // a second candidate, or the only one shares the trigram
+                    v = okm[j] ? v : 0xffffffffu;
+                    const bool push = v == scan[j];
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(push);
+                    if (push) wl[nl + rank_in(m)] = (uint16_t)(q0 + j);
                     nl += (uint32_t)__popcll(m);
                 }
             }
@@ -1025,7 +1040,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         if (M) {                                     // this block's match starts are final: their records go out, selected and compact
             if ((M >> lane) & 1ull) {
                 const uint2 e = m.win[q & 127u];
-                chosen[n_match + (uint32_t)__popcll(M & lanes_below())] = ((M32 >> lane) & 1ull) ? e.y : e.x;
+                chosen[n_match + rank_in(M)] = ((M32 >> lane) & 1ull) ? e.y : e.x;
             }
             n_match += (uint32_t)__popcll(M);
         }
@@ -1628,7 +1643,7 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
             const uint32_t p = seg + (it << 6) + lane;
             if (p < seg_end) {
                 byte = data[p];
-                if ((mw >> lane) & 1ull) e = chosen[mfirst + (uint32_t)__popcll(mw & lanes_below())];   // dense: 4 bytes per match
+                if ((mw >> lane) & 1ull) e = chosen[mfirst + rank_in(mw)];   // dense: 4 bytes per match
             }
         };
         auto block_of = [&](uint32_t p) { return (uint32_t)(p >= b1) + (uint32_t)(p >= b2) + (uint32_t)(p >= b3) + (uint32_t)(p >= b4); };
@@ -1888,7 +1903,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     // ~100 scalar instructions per slot -- and the scalar unit is what this kernel runs out of)
                     const uint32_t kd = inf[r] & 7u;
                     const uint32_t mk = (uint32_t)(M[r] >> lane) & 1u;
-                    const uint32_t rank = base + (uint32_t)__popcll(M[r] & lanes_below());
+                    const uint32_t rank = base + rank_in(M[r]);
                     const uint32_t is_lit = (uint32_t)(kd == kLit), is_match = (uint32_t)(kd == kMatch), mlen = val[r] >> 16;
                     const uint32_t ol = mk * (is_lit + is_match * mlen);
                     const uint32_t sc = wave_scan_incl(ol);
