@@ -4,7 +4,6 @@
 
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -70,11 +69,14 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = configure_kernels();
     if (e == hipSuccess) {
-        // lz_links flavour: the one-exchange-per-step kernel where the device's LDS exchange behaves as it needs (checked
-        // here, once per context), the read/write/read-back kernel otherwise or when ZWZ_LINKS=pair asks for it
-        const char* want = getenv("ZWZ_LINKS");
-        if (want && !strcmp(want, "pair")) c->links_xchg = false;
-        else e = probe_exchange_order(c->stream, &c->links_xchg);
+        // lz_links stands on the lane order of the LDS exchange (see exchange_order_probe_kernel): checked once per context
+        bool holds = false;
+        e = probe_exchange_order(c->stream, &holds);
+        if (e == hipSuccess && !holds) {
+            set_error("zwz_ctx_create: this device's ds_wrxchg_rtn_b32 does not serve same-address lanes in lane order; lz_links cannot run on it");
+            zwz_ctx_destroy(c);
+            return ZWZ_E_NO_DEVICE;
+        }
     }
     for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
@@ -261,7 +263,6 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
     a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
-    a.links_xchg = c->links_xchg ? 1u : 0u;
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
     a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));

@@ -16,7 +16,6 @@ struct zwz_ctx {
     void* h_stage = nullptr;
     uint32_t stage_chunks = 0;
     bool profiling = false;
-    bool links_xchg = false;         // lz_links flavour, settled in zwz_ctx_create
     hipEvent_t ev[zwz::kNumDeflateStages + 1] = {};
     hipEvent_t ev_inf[2] = {};
     float stage_ms[ZWZ_NUM_STAGES] = {};

@@ -11,10 +11,8 @@ namespace zwz {
 // Per-chunk strides of the intermediates (elements).  Everything is indexed [chunk][position].
 constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
 constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
-constexpr uint32_t kLinksThreads = 128;                            // one inserter wave + one feeder wave per chunk
-constexpr uint32_t kLinksXThreads = 320;                           // exchange flavour: one inserter wave + four feeder waves
-constexpr uint32_t kLinksXLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // exchange flavour: 32-bit buckets, 32-bit buffer entries
-constexpr uint32_t kLinksLdsBytes = 65536 + 16 + 2 * 2048 * 2 + 256;  // head table + dummy slot + two hash/link buffers + slack for read-ahead
+constexpr uint32_t kLinksThreads = 320;                            // one inserter wave + four feeder waves per chunk
+constexpr uint32_t kLinksLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // 32-bit head table + spare slot + two bucket-address/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
@@ -69,7 +67,6 @@ struct DeflateArgs {
     // workspace (sized for n chunks)
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
-    uint32_t links_xchg;       // lz_links flavour: 1 = one exchange per step on 32-bit buckets (ZWZ_LINKS, see zwz_api.cpp)
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space

@@ -21,6 +21,8 @@
 // All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "huff_core.h"
 #include "inflate_core.h"
 #include "lz_core.h"
@@ -62,53 +64,36 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 
 // ------------------------------------------------------------------------------------------------
 // lz_links: link[p] = newest position q < p with hash3(q) == hash3(p), 0 if none (zlib NIL).
-// The chain insert is sequential in the position: one wave walks the chunk 64 positions a step with
-// the 64 KiB head table in LDS -- and a lone wave issues an instruction every ~6 cycles, so a step
-// costs what its instruction count says (the first version: ~45 instructions, 270 cycles, with two
-// of a CU's four SIMDs idle because two head tables fill its LDS).  So the work of a step is split
-// over two waves of a workgroup, on two SIMDs:
-//   wave 1 (feeder): input bytes -> hash values of the next 2048 positions into an LDS buffer, and
-//           the finished links of the previous 2048 positions out of that buffer to HBM, both as
-//           16-byte vectors;
-//   wave 0 (inserter): per step one hash read, the head read / write / read-back, the collision
-//           check, one link write -- 13 instructions.
-// The two meet at a barrier every 2048 positions (two buffers alternate).  What the feeder hands over is
-// each position's bucket ADDRESS (2 x hash: one instruction less on the inserter's critical path).
-// Positions past the last trigram are sent to bucket 0: they are the last positions of the chunk, nothing
-// reads the table after them, and the feeder zeroes their links on the way out -- so the inserter needs
-// no validity logic.
-//
-// The inserter's steady state is one block of inline asm (insert_block): three register sets take turns,
-// step t's three LDS operations and the hash read of step t+2 are issued before step t-2's read-back is
-// looked at, and "it is back" is a counted wait (LDS returns in order: lgkmcnt(10) = ten younger operations
-// may still be out).  The compiler's own wait insertion drains to 0 at loop headers and right behind loads
-// it schedules early, which is why this is asm; what keeps it sound:
-//   * every step issues exactly the same operations in the same order, whatever its lanes hold;
+// The chain insert is sequential in the position: one wave (the inserter) walks the chunk 64 positions a step with the
+// head table in LDS.  A step is ONE LDS operation: with 32-bit buckets, ds_wrxchg_rtn_b32 stores the 64 positions into
+// their buckets and hands each lane its predecessor -- lanes that name the same bucket are served in ascending lane
+// order (each gets what the nearest lower one wrote, the lowest the old bucket value, the highest lane's position stays),
+// which is zlib's insert-in-position-order: no read-back, no collision repair, the same cost on text as on random bytes.
+// The ISA manual does not promise that order; zwz_ctx_create checks it on the device (exchange_order_probe_kernel) and
+// refuses to create a context where it does not hold.  (The round's earlier kernel -- 16-bit buckets, head read / write /
+// read-back per step with collision repair -- took 5.8 ms per 50 000 chunks on random bytes and 35.6 ms on text, where
+// most steps hold colliding hashes.)
+// A lone wave issues an instruction every ~6 cycles, so everything but the exchange is kept off the inserter: four feeder
+// waves turn input bytes into the bucket ADDRESSES of the next 2048 positions in an LDS buffer and move the finished links
+// of the previous 2048 positions out of that buffer to HBM, both as 16-byte vectors; the two roles meet at a barrier
+// every 2048 positions (two buffers alternate).  Positions past the last trigram are sent to bucket 0: they are the last
+// positions of the chunk, nothing reads the table after them, and the feeders zero their links on the way out -- so the
+// inserter needs no validity logic.  The 128 KiB table leaves room for one chunk per CU.
+// The compiler's own wait insertion drains to 0 at loop headers and right behind loads it schedules early, which is why the
+// inserter's loop and the feeders' input loads are inline asm with counted waits; what keeps that sound:
+//   * every step / hand-over issues exactly the same operations in the same order, whatever its lanes hold;
 //   * no in-flight register is read, copied or merged before the wait that covers it;
-//   * the loop is entered with nothing in flight and left through a full drain.
-// A collision inside a step (two lanes, one hash: 6 % of the steps on random bytes) is repaired in place
-// by the lane whose store lost (insert_block); anything more -- several losers, a later step holding the
-// same hash -- drains and goes through the general repair in C++, and blocks in which that keeps
-// happening (text) run a plain one-step-at-a-time loop instead (insert_block_dense).
-//
-// That is the "pair" flavour (lz_links_kernel<false>), kept as the fallback.  The flavour a context normally runs
-// (lz_links_kernel<true>, chosen in zwz_ctx_create after exchange_order_probe_kernel has passed on the device) needs none of
-// the collision machinery: with 32-bit buckets one ds_wrxchg_rtn_b32 per step both stores the positions and returns each
-// lane's predecessor, same-address lanes being served in ascending lane order -- zlib's insert order.  Its cost is
-// data-independent, 64 cycles a step (the LDS retires an exchange one lane a cycle), the same on text and on random bytes:
-// 5.4 ms per 50 000 chunks against 5.8 / 35.6 ms.  The 128 KiB table leaves room for one chunk per CU, so the feeder's work
-// is spread over four waves (8 positions a lane a block) to keep it off the critical path.
+//   * the loops are entered with nothing in flight (inserter) or a known number of operations in flight (feeders).
 constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
 constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (see below: any bucket will do)
 
-template <bool kXchg>
-__global__ __launch_bounds__(kXchg ? kLinksXThreads : kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+__global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
                                                                  uint32_t* __restrict__ link_stat) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
-    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 entries (kXchg: 32-bit ones) + 16 spare bytes
-    constexpr uint32_t kHeadBytes = kXchg ? 131072u : 65536u;
+    extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 32-bit buckets + 16 spare bytes
+    constexpr uint32_t kHeadBytes = 131072u;
     uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock: hashes in, links out
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t L = in_len[chunk];
@@ -119,41 +104,49 @@ __global__ __launch_bounds__(kXchg ? kLinksXThreads : kLinksThreads) void lz_lin
     const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
 
     uint4* h4 = reinterpret_cast<uint4*>(head);
-    constexpr uint32_t kThreads = kXchg ? kLinksXThreads : kLinksThreads;
-    for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kThreads) h4[i] = make_uint4(0, 0, 0, 0);
-    if (kXchg && tid == 0) link_stat[chunk] = 0;       // the feeder waves add their counts at the end
+    for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) link_stat[chunk] = 0;       // the feeder waves add their counts at the end
 
-    // ---- feeder
-    // the feeder keeps the next block's input in registers, loaded one hand-over ahead: a block's ~2 us of HBM
-    // latency is then hidden behind the previous block's work (issued and consumed in the same hand-over it was the
-    // critical path of the whole kernel: 5 k cycles per block against the inserter's 2.5 k)
-    constexpr uint32_t kFeeders = kXchg ? (kLinksXThreads / 64u - 1u) : 1u;    // feeder waves, each with its own share of every block
+    // ---- feeder: input bytes -> registers (asked for hand-overs ahead, see the main loop) -> bucket addresses in LDS;
+    // finished links LDS -> HBM
+    constexpr uint32_t kFeeders = kLinksThreads / 64u - 1u;    // feeder waves, each with its own share of every block
     constexpr uint32_t kPer = 32u / kFeeders;         // positions per feeder lane per block
-    constexpr uint32_t kW = kPer / 4u;
-    uint32_t in_w[kW + 1];
+    // Input register sets.  A block's bytes are asked for three hand-overs before their use, by inline asm: left to the
+    // compiler, the wait in front of the first use was vmcnt(0/1) -- everything but the link store just issued, including
+    // the request made one hand-over ago -- and each hand-over again lasted one HBM round trip.  VMEM operations complete
+    // in order, so "the set asked for three trips ago has landed" is a counted wait, provided every trip issues the same
+    // operations: load_block always issues its loads (a part past the readable end is not needed -- its positions have no
+    // trigram -- and is read from the chunk's start instead), and where a trip has no links to write out it stores zeros
+    // over links that are written later (pad_stores).  The sets must also stay where they are while a load is in flight:
+    // they only ever pass through unconditional asm statements ("+v"), in loops of their own.
+    constexpr uint32_t kAhead = 3;
+    static_assert(kPer == 8u, "the feeder below is written for eight positions a lane: an 8-byte and a 4-byte load, one 16-byte link store");
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    struct InSet { v2u c; uint32_t t; };               // input bytes [o, o + 8) and [o + 8, o + 12) of a lane's share
+    InSet in_ring[kAhead];
 #pragma unroll
-    for (uint32_t j = 0; j <= kW; j++) in_w[j] = 0;
+    for (uint32_t r = 0; r < kAhead; r++) { in_ring[r].c = 0; in_ring[r].t = 0; }
+    constexpr uint32_t kLoadOps = 2u;                                           // VMEM operations of a load_block ...
+    constexpr uint32_t kStoreOps = 1u;                                          // ... and of a flush_block
+    constexpr uint32_t kWait = 2u * (kLoadOps + kStoreOps) + kStoreOps;         // operations younger than the awaited set: two whole trips and this trip's store
     const uint32_t fpos = (wave - 1u) * (kLinksBlock / kFeeders) + lane * kPer;   // this lane's share within a block (feeder waves)
-    auto load_block = [&](uint32_t k) {            // input bytes [2048 k + fpos, + kPer + 4) -> in_w
+    auto load_block = [&](uint32_t k, auto slot) { // input bytes [2048 k + fpos, + 12) -> register set `slot` (= k mod kAhead)
+        InSet& S = in_ring[decltype(slot)::value];
         const uint32_t o = k * kLinksBlock + fpos;
-        const uint4* g = reinterpret_cast<const uint4*>(data + o);
-        if (kW == 2u) {
-            uint2 v = make_uint2(0, 0);
-            if (o + 8u <= Lr) v = *reinterpret_cast<const uint2*>(data + o);
-            in_w[0] = v.x; in_w[1] = v.y;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kW / 4u; j++) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (o + 16u * j + 16u <= Lr) v = g[j];
-            in_w[4 * j] = v.x; in_w[4 * j + 1] = v.y; in_w[4 * j + 2] = v.z; in_w[4 * j + 3] = v.w;
-        }
-        in_w[kW] = 0;
-        if (o + kPer + 4u <= Lr) in_w[kW] = reinterpret_cast<const uint32_t*>(data + o)[kW];
+        const uint8_t* pa = data + (o + 8u <= Lr ? o : 0u);
+        const uint8_t* pt = data + (o + 12u <= Lr ? o + 8u : 0u);
+        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
+    };
+    auto pad_stores = [&](uint32_t n) {            // n stores with no effect: zeros over this lane's first link of block 0, before its flush_block writes it
+        for (uint32_t i = 0; i < n; i++) asm volatile("global_store_short %0, %1, off" :: "v"(lk + fpos), "v"(0u) : "memory");
     };
     typedef __attribute__((address_space(3))) uint8_t* lds_byte_ptr;
     const uint32_t head_base = (uint32_t)(uintptr_t)(lds_byte_ptr) reinterpret_cast<uint8_t*>(head);   // 0: this kernel has no static LDS
-    auto hash_block = [&](uint32_t k) {            // bucket addresses of positions [2048 k + fpos, + kPer) from the loaded input
+    uint32_t* hbuf32 = reinterpret_cast<uint32_t*>(hbuf);                       // 32-bit entries: bucket address in, link out
+    auto hash_block = [&](uint32_t k, auto slot) { // bucket addresses of positions [2048 k + fpos, + 8) from the loaded input
+        InSet& S = in_ring[decltype(slot)::value];
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.c), "+v"(S.t) : "n"(kWait) : "memory");
+        const uint32_t in_w[3] = {S.c.x, S.c.y, S.t};
         const uint32_t o = k * kLinksBlock + fpos;
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
         uint32_t e[kPer];
@@ -162,289 +155,38 @@ __global__ __launch_bounds__(kXchg ? kLinksXThreads : kLinksThreads) void lz_lin
             const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(in_w[(i >> 2) + 1], in_w[i >> 2], i & 3u) : in_w[i >> 2];
             uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
             if (i >= n_ok) h = kLinksNoHash;
-            e[i] = (kXchg ? 4u : 2u) * h + head_base;  // the bucket's LDS byte address (2-byte buckets: fits 16 bits, the table starts at LDS address 0)
+            e[i] = 4u * h + head_base;                 // the bucket's LDS byte address
         }
-        if (kXchg) {                                   // 32-bit entries
-            uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(hbuf) + (k & 1u) * kLinksBlock + fpos);
-#pragma unroll
-            for (uint32_t j = 0; j < kPer / 4u; j++) dst[j] = make_uint4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
-        } else {
-            uint4* dst = reinterpret_cast<uint4*>(hbuf + (k & 1u) * kLinksBlock + fpos);
-#pragma unroll
-            for (uint32_t j = 0; j < kPer / 8u; j++)
-                dst[j] = make_uint4(e[8 * j] | e[8 * j + 1] << 16, e[8 * j + 2] | e[8 * j + 3] << 16, e[8 * j + 4] | e[8 * j + 5] << 16, e[8 * j + 6] | e[8 * j + 7] << 16);
-        }
+        uint4* dst = reinterpret_cast<uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);
+        dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
+        dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
     };
     uint32_t linked = 0;                               // feeder: positions of this lane with a chain predecessor
     auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
         const uint32_t o = k * kLinksBlock + fpos;
-        const uint4* src = reinterpret_cast<const uint4*>(hbuf + (k & 1u) * kLinksBlock + fpos);
-        const uint4* s32 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(hbuf) + (k & 1u) * kLinksBlock + fpos);
-        uint4* dst = reinterpret_cast<uint4*>(lk + o);
+        const uint4* src = reinterpret_cast<const uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;
+        const uint4 lo = src[0], hi = src[1];          // 32-bit slots, the link in each one's low half
+        uint4 v = make_uint4((lo.x & 0xffffu) | lo.y << 16, (lo.z & 0xffffu) | lo.w << 16, (hi.x & 0xffffu) | hi.y << 16, (hi.z & 0xffffu) | hi.w << 16);
+        if (n_ok < kPer) {                             // rare: the chunk's last positions
+            uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < kPer / 8u; j++) {
-            uint4 v;
-            if (kXchg) {                           // 32-bit slots, the link in each one's low half
-                const uint4 lo = s32[2 * j], hi = s32[2 * j + 1];
-                v = make_uint4((lo.x & 0xffffu) | lo.y << 16, (lo.z & 0xffffu) | lo.w << 16, (hi.x & 0xffffu) | hi.y << 16, (hi.z & 0xffffu) | hi.w << 16);
-            } else v = src[j];
-            if (n_ok < 8u * j + 8u) {              // rare: the chunk's last positions
-                uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (uint32_t q = 0; q < 4; q++) {
-                    const uint32_t i0 = 8u * j + 2u * q;
-                    if (i0 >= n_ok) e[q] = 0; else if (i0 + 1u >= n_ok) e[q] &= 0xffffu;
-                }
-                v = make_uint4(e[0], e[1], e[2], e[3]);
+            for (uint32_t q = 0; q < 4; q++) {
+                if (2u * q >= n_ok) e[q] = 0; else if (2u * q + 1u >= n_ok) e[q] &= 0xffffu;
             }
-            dst[j] = v;
-            linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0)
-                    + (uint32_t)((v.z & 0xffffu) != 0) + (uint32_t)((v.z >> 16) != 0) + (uint32_t)((v.w & 0xffffu) != 0) + (uint32_t)((v.w >> 16) != 0);
+            v = make_uint4(e[0], e[1], e[2], e[3]);
         }
+        *reinterpret_cast<uint4*>(lk + o) = v;
+        linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0)
+                + (uint32_t)((v.z & 0xffffu) != 0) + (uint32_t)((v.z >> 16) != 0) + (uint32_t)((v.w & 0xffffu) != 0) + (uint32_t)((v.w >> 16) != 0);
     };
 
     // ---- inserter
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
     const uint32_t head_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(head));   // LDS byte addresses
     const uint32_t hbuf_a = head_a + kHeadBytes + 16u;
-    struct Step { uint32_t p16, prev, rb; };           // position, head read, read-back of one 64-position step
-    auto lds_u16 = [&](uint32_t addr) -> uint32_t {    // complete on return
-        uint32_t v;
-        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-        return v;
-    };
-    auto issue_and_wait = [&](Step& S, uint32_t h) {   // the slow path's version of a step's three operations
-        const uint32_t bucket = h;                    // the buffer holds bucket addresses
-        asm volatile("ds_read_u16 %0, %2\n\tds_write_b16 %2, %3\n\tds_read_u16 %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(S.prev), "=&v"(S.rb) : "v"(bucket), "v"(S.p16) : "memory");
-    };
-    // Collision repair of a complete step S.  Up to two later steps (N1, then N2) have been issued behind it and are
-    // complete too; a step's hashes sit in its buffer slots until its links replace them.
-    // Lanes of S sharing a hash all read the old head and one arbitrary store won: every lane but the lowest of a
-    // group links to its next lower peer, and the bucket belongs to the newest peer -- unless a later step already
-    // stored a newer position there.  The first later step holding that hash read an arbitrary peer of S with its
-    // lowest such lane, which gets the newest peer instead (its other lanes, and whatever N2 read from N1's stores,
-    // are that step's own repair).
-    auto repair = [&](Step& S, uint32_t slot_s, bool has1, Step& N1, bool has2, Step& N2) {
-        uint64_t dup = __builtin_amdgcn_uicmp(S.rb, S.p16, 33 /* ICMP_NE */);
-        if (dup == 0) return;
-        const uint32_t h_s = lds_u16(slot_s);
-        const uint32_t h_1 = has1 ? lds_u16(slot_s + 128u) : 0xffffffffu, h_2 = has2 ? lds_u16(slot_s + 256u) : 0xffffffffu;
-        const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(S.p16);
-        while (dup) {  // wave-uniform: one iteration per hash value shared inside step S
-            const uint32_t l = (uint32_t)__builtin_ctzll(dup);
-            const uint32_t hh = __builtin_amdgcn_readlane(h_s, l);
-            const uint64_t peers = __builtin_amdgcn_uicmp(h_s, hh, 32 /* ICMP_EQ */);
-            const uint32_t top = 63u - (uint32_t)__builtin_clzll(peers), newest = p_lane0 + top;
-            if (h_s == hh) {
-                const uint64_t lower = peers & lanes_below();
-                if (lower) S.prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
-            }
-            const uint64_t a1 = __builtin_amdgcn_uicmp(h_1, hh, 32), a2 = __builtin_amdgcn_uicmp(h_2, hh, 32);
-            if (a1) { if (lane == (uint32_t)__builtin_ctzll(a1)) N1.prev = newest; }
-            else if (a2) { if (lane == (uint32_t)__builtin_ctzll(a2)) N2.prev = newest; }
-            else if (lane == top) head[(hh - head_a) >> 1] = (uint16_t)newest;    // newest peer owns the bucket (hh is its byte address)
-            dup &= ~peers;
-        }
-    };
-    auto write_link = [&](uint32_t slot, uint32_t prev) {   // the link replaces the hash in the buffer
-        asm volatile("ds_write_b16 %0, %1" :: "v"(slot), "v"(prev) : "memory");     // no wait: LDS is in order, readers wait for themselves
-    };
-    uint32_t slow_exits = 0;                          // collisions of the last block that needed the general repair
+    // one exchange per step (see the kernel's header)
     auto insert_block = [&](uint32_t k) {
-        slow_exits = 0;
-        const uint32_t first = k * kLinksBlock;
-        const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);      // >= 1
-        uint32_t base = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);                    // this lane's buffer entry of step s
-        Step P0, P1, P2;
-        uint32_t s = 0;                                                                   // P0 = step s, P1 = step s + 1: issued, complete
-        P0.p16 = first + lane; P1.p16 = P0.p16 + 64u; P2.p16 = P0.p16 + 128u;
-        uint32_t h0 = 0, h1 = 0, h2 = 0;
-        bool primed = false;                                                              // hs0, hs1, h2, h0 hold the four hashes the loop starts from
-        uint32_t hs0 = 0, hs1 = 0, hs2 = 0;
-        if (n_steps >= 5u) {
-            // block start in two LDS round trips: the hashes of steps 0..3 at once, then steps 0 and 1 back to back
-            asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\t"
-                         "s_waitcnt lgkmcnt(0)" : "=&v"(hs0), "=&v"(hs1), "=&v"(h2), "=&v"(h0) : "v"(base) : "memory");
-            const uint32_t b0 = hs0, b1 = hs1;
-            asm volatile("ds_read_u16 %0, %4\n\tds_write_b16 %4, %6\n\tds_read_u16 %1, %4\n\t"
-                         "ds_read_u16 %2, %5\n\tds_write_b16 %5, %7\n\tds_read_u16 %3, %5\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(P0.prev), "=&v"(P0.rb), "=&v"(P1.prev), "=&v"(P1.rb) : "v"(b0), "v"(b1), "v"(P0.p16), "v"(P1.p16) : "memory");
-            primed = true;
-        } else {
-            issue_and_wait(P0, lds_u16(base));
-            if (n_steps > 1) issue_and_wait(P1, lds_u16(base + 128u));
-        }
-        for (;;) {
-            uint32_t left = __builtin_amdgcn_readfirstlane(n_steps > s + 2u ? n_steps - 2u - s : 0u);   // steps not issued yet
-            if (left < 3u) break;
-            if (!primed) {
-                // (re-)entry after a general repair: hashes of the steps in P0, P1 (still in their slots) and of the next two to issue
-                asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\t"
-                             "s_waitcnt lgkmcnt(0)" : "=&v"(hs0), "=&v"(hs1), "=&v"(h2), "=&v"(h0) : "v"(base) : "memory");
-            }
-            primed = false;
-            // Steady state, three steps a trip (three register sets take turns), entered with nothing in flight.  Per
-            // step t: the hashes of step t+2 are read, the three operations of step t are issued, and only then is the
-            // read-back of step t-2 looked at -- two steps of other work cover every LDS round trip.  LDS returns in
-            // order, so both "the hashes of t are back" and "step t-2 is back" are lgkmcnt(10): that many younger
-            // operations sit in the queue behind them.
-            // A collision inside the retiring step (two lanes, one hash: 6 % of the steps on random bytes) is repaired
-            // in place by the lane whose store lost -- its read-back names the winner: if the winner is the higher
-            // lane the bucket is right and only the winner's link (already written to its buffer slot) must become
-            // the loser's position; if the winner is the lower lane the loser links to it and re-stores itself in the
-            // bucket.  Anything else (several losers, a later step already holding that hash) goes out to C++.
-            uint32_t code, bk, t32, hh; uint64_t dm, sv;
-            // issue step t (hashes HC, read two steps ago), read the hashes of step t+2, retire step t-2
-#define ZWZ_LINK_STEP(HN, HN_OFF, HC, HSC, PC, RC, PPOS, PR, RR, RPOS, ROFF, FIX, BACK)              \
-                "ds_read_u16 %[" HN "], %[base] offset:" HN_OFF "\n\t"                                 \
-                "s_waitcnt lgkmcnt(10)\n\t"                                                          \
-                "v_mov_b32 %[" HSC "], %[" HC "]\n\t"                                                \
-                "ds_read_u16 %[" PC "], %[" HSC "]\n\t"                                              \
-                "ds_write_b16 %[" HSC "], %[" PPOS "]\n\t"                                           \
-                "ds_read_u16 %[" RC "], %[" HSC "]\n\t"                                                   \
-                "s_waitcnt lgkmcnt(10)\n\t"                                                          \
-                "v_cmp_ne_u32 vcc, %[" RR "], %[" RPOS "]\n\t"                                       \
-                "s_cbranch_vccnz " FIX "f\n\t"                                                       \
-                "ds_write_b16 %[base], %[" PR "] offset:" ROFF "\n\t"                                \
-                BACK ":\n\t"                                                                         \
-                "v_add_u32 %[" RPOS "], 0xc0, %[" RPOS "]\n\t"
-            // out of line: the loser lane's repair (then back into the loop), or out to C++
-#define ZWZ_LINK_FIX(FIX, BACK, PR, RR, RPOS, ROFF, HSR, HS1, HS2, EXIT)                             \
-                FIX ":\n\t"                                                                          \
-                "s_mov_b64 %[dm], vcc\n\t"                                                           \
-                "s_bcnt1_i32_b64 %[t32], vcc\n\t"                                                    \
-                "s_cmp_eq_u32 %[t32], 1\n\t"                                                         \
-                "s_cbranch_scc0 " EXIT "f\n\t"                                                       \
-                "s_ff1_i32_b64 %[t32], vcc\n\t"                                                      \
-                "v_readlane_b32 %[hh], %[" HSR "], %[t32]\n\t"                                       \
-                "v_cmp_eq_u32 vcc, %[hh], %[" HS1 "]\n\t"                                            \
-                "s_cbranch_vccnz " EXIT "f\n\t"                                                      \
-                "v_cmp_eq_u32 vcc, %[hh], %[" HS2 "]\n\t"                                            \
-                "s_cbranch_vccnz " EXIT "f\n\t"                                                      \
-                "s_and_saveexec_b64 %[sv], %[dm]\n\t"                                                \
-                "v_cmp_gt_u32 vcc, %[" RR "], %[" RPOS "]\n\t"                                       \
-                "v_cndmask_b32 %[" PR "], %[" RR "], %[" PR "], vcc\n\t"                             \
-                "v_sub_u32 %[bk], %[" RR "], %[" RPOS "]\n\t"                                        \
-                "v_lshl_add_u32 %[bk], %[bk], 1, %[base]\n\t"                                        \
-                "s_mov_b64 exec, %[sv]\n\t"                                                          \
-                "ds_write_b16 %[base], %[" PR "] offset:" ROFF "\n\t"                                \
-                "s_and_b64 exec, %[dm], vcc\n\t"                                                     \
-                "ds_write_b16 %[bk], %[" RPOS "] offset:" ROFF "\n\t"                                \
-                "s_andn2_b64 exec, %[dm], vcc\n\t"                                                   \
-                "ds_write_b16 %[" HSR "], %[" RPOS "]\n\t"                                                \
-                "s_mov_b64 exec, %[sv]\n\t"                                                          \
-                "s_branch " BACK "b\n\t"
-            asm volatile(
-                "1:\n\t"
-                ZWZ_LINK_STEP("h1", "512", "h2", "hs2", "prev2", "rb2", "p2", "prev0", "rb0", "p0", "0", "20", "30")      /* issue s+2, retire s */
-                ZWZ_LINK_STEP("h2", "640", "h0", "hs0", "prev0", "rb0", "p0", "prev1", "rb1", "p1", "128", "21", "31")    /* issue s+3, retire s+1 */
-                ZWZ_LINK_STEP("h0", "768", "h1", "hs1", "prev1", "rb1", "p1", "prev2", "rb2", "p2", "256", "22", "32")    /* issue s+4, retire s+2 */
-                "v_add_u32 %[base], 0x180, %[base]\n\t"
-                "s_sub_u32 %[left], %[left], 3\n\t"
-                "s_cmp_gt_u32 %[left], 2\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_mov_b32 %[code], 3\n\t"
-                "s_branch 9f\n\t"
-                ZWZ_LINK_FIX("20", "30", "prev0", "rb0", "p0", "0", "hs0", "hs1", "hs2", "5")
-                ZWZ_LINK_FIX("21", "31", "prev1", "rb1", "p1", "128", "hs1", "hs2", "hs0", "6")
-                ZWZ_LINK_FIX("22", "32", "prev2", "rb2", "p2", "256", "hs2", "hs0", "hs1", "7")
-                "5:\n\t"
-                "s_mov_b32 %[code], 0\n\t"
-                "s_branch 9f\n\t"
-                "6:\n\t"
-                "s_mov_b32 %[code], 1\n\t"
-                "s_branch 9f\n\t"
-                "7:\n\t"
-                "s_mov_b32 %[code], 2\n\t"
-                "9:\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [hs0] "+v"(hs0), [hs1] "+v"(hs1), [hs2] "+v"(hs2),
-                  [prev0] "+v"(P0.prev), [rb0] "+v"(P0.rb), [prev1] "+v"(P1.prev), [rb1] "+v"(P1.rb),
-                  [prev2] "+v"(P2.prev), [rb2] "+v"(P2.rb), [p0] "+v"(P0.p16), [p1] "+v"(P1.p16), [p2] "+v"(P2.p16), [base] "+v"(base),
-                  [left] "+s"(left), [code] "=&s"(code), [bk] "=&v"(bk), [t32] "=&s"(t32), [hh] "=&s"(hh), [dm] "=&s"(dm), [sv] "=&s"(sv)
-                : [head] "s"(head_a)
-                : "vcc", "scc", "memory");
-#undef ZWZ_LINK_FIX
-#undef ZWZ_LINK_STEP
-            s = n_steps - 2u - left;                   // step held by P0 when the interrupted (or last) trip began
-            if (code == 3u) break;                     // P0 = step s, P1 = step s+1 complete
-            slow_exits++;
-            if (code == 0u) {
-                // collision in step s (P0); P1 = s+1 and P2 = s+2 are issued; h0 = hashes of s + 3
-                repair(P0, base, true, P1, true, P2);
-                write_link(base, P0.prev);
-                P0 = P1; P1 = P2; P2.p16 = P1.p16 + 64u;
-                s += 1u; base += 128u;
-            } else if (code == 1u) {
-                // collision in step s+1 (P1); link of s written; P2 = s+2 and P0 = s+3 are issued; h1 = hashes of s + 4
-                repair(P1, base + 128u, true, P2, true, P0);
-                write_link(base + 128u, P1.prev);
-                const Step t = P0; P0 = P2; P1 = t; P2.p16 = P1.p16 + 64u;
-                s += 2u; base += 256u;
-            } else {
-                // collision in step s+2 (P2); links of s, s+1 written; P0 = s+3 and P1 = s+4 are issued; h2 = hashes of s + 5
-                repair(P2, base + 256u, true, P0, true, P1);
-                write_link(base + 256u, P2.prev);
-                P2.p16 = P1.p16 + 64u;
-                s += 3u; base += 384u;
-            }
-        }
-        // fewer than three steps left to issue: one at a time.  P0 = step s and (if it exists) P1 = step s+1 are complete.
-        while (s + 1u < n_steps) {
-            repair(P0, base, true, P1, false, P1);
-            write_link(base, P0.prev);
-            P0 = P1; s += 1u; base += 128u;
-            if (s + 1u < n_steps) { P1.p16 = P0.p16 + 64u; issue_and_wait(P1, lds_u16(base + 128u)); }
-        }
-        repair(P0, base, false, P0, false, P0);
-        write_link(base, P0.prev);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the feeder reads these links right after the barrier
-    };
-
-    // Collision-dense data (text: most steps hold several repeated trigrams): every step would leave the pipelined
-    // loop, so such blocks run one step at a time -- nothing is ever issued behind the step under repair.
-    auto insert_block_dense = [&](uint32_t k) {
-        const uint32_t first = k * kLinksBlock;
-        const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);
-        uint32_t base = hbuf_a + 2u * ((k & 1u) * kLinksBlock + lane);
-        Step P; P.p16 = first + lane;
-        uint32_t h = lds_u16(base), collided = 0;
-        for (uint32_t st = 0; st < n_steps; st++) {
-            uint32_t hn;
-            const uint32_t bucket = h;
-            asm volatile("ds_read_u16 %0, %3 offset:128\n\tds_read_u16 %1, %4\n\tds_write_b16 %4, %5\n\tds_read_u16 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(hn), "=&v"(P.prev), "=&v"(P.rb) : "v"(base), "v"(bucket), "v"(P.p16) : "memory");
-            uint64_t dup = __builtin_amdgcn_uicmp(P.rb, P.p16, 33 /* ICMP_NE */);
-            if (dup) {
-                collided++;
-                const uint32_t p_lane0 = __builtin_amdgcn_readfirstlane(P.p16);
-                while (dup) {  // wave-uniform: one iteration per hash value shared inside the step
-                    const uint32_t hh = __builtin_amdgcn_readlane(h, (uint32_t)__builtin_ctzll(dup));
-                    const uint64_t peers = __builtin_amdgcn_uicmp(h, hh, 32 /* ICMP_EQ */);
-                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(peers);
-                    if (h == hh) {
-                        const uint64_t lower = peers & lanes_below();
-                        if (lower) P.prev = p_lane0 + 63u - (uint32_t)__builtin_clzll(lower);
-                        if (lane == top) head[(hh - head_a) >> 1] = (uint16_t)P.p16;   // newest peer owns the bucket
-                    }
-                    dup &= ~peers;
-                }
-            }
-            asm volatile("ds_write_b16 %0, %1" :: "v"(base), "v"(P.prev) : "memory");
-            h = hn; P.p16 += 64u; base += 128u;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        slow_exits = collided;                            // stay dense while most steps collide
-    };
-
-    // ---- inserter, exchange flavour (kXchg): 32-bit buckets and ONE operation per step.  ds_wrxchg_rtn_b32 hands every lane
-    // the value the nearest lower lane with the same address wrote (the old bucket value to the lowest) and leaves the highest
-    // lane's value behind -- measured on gfx950 (tools/exp/xchg_order.hip), and probed again at context creation -- which is
-    // exactly zlib's insert-in-position-order: no read-back, no collisions to repair, whatever the data.  The price is a
-    // 128 KiB table: one chunk per CU instead of two.
-    auto insert_block_x = [&](uint32_t k) {
         const uint32_t first = k * kLinksBlock;
         const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);      // >= 1
         uint32_t base = hbuf_a + 4u * ((k & 1u) * kLinksBlock + lane);                    // this lane's buffer entry of step s
@@ -498,35 +240,52 @@ __global__ __launch_bounds__(kXchg ? kLinksXThreads : kLinksThreads) void lz_lin
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the feeder reads these links right after the barrier
     };
 
+    // The feeder's input comes from HBM, ~1.5 us away under load, and a hand-over lasts half of that: with the bytes of
+    // block k + 2 asked for one hand-over ahead of their use every hand-over waited for them (4.8 of the kernel's 5.4 ms
+    // with the inserter switched off).  Three register sets take turns, so a request has three hand-overs to land.
+    using Slot0 = std::integral_constant<uint32_t, 0>; using Slot1 = std::integral_constant<uint32_t, 1>; using Slot2 = std::integral_constant<uint32_t, 2>;
     __syncthreads();
     if (wave >= 1) {
-        load_block(0);
-        hash_block(0);
-        if (n_blocks > 1) load_block(1);
+        load_block(0, Slot0{});
+        load_block(1, Slot1{});
+        load_block(2, Slot2{});
+        pad_stores(3u * kStoreOps);                 // (the counted wait assumes two earlier trips)
+        hash_block(0, Slot0{});
+        load_block(3, Slot0{});
     }
     __syncthreads();
-    for (uint32_t k = 0; k < n_blocks; k++) {
-        if (wave == 0) {
-            if (kXchg) insert_block_x(k);
-            else if (slow_exits >= 6u) insert_block_dense(k);
-            else insert_block(k);
-        }
-        else {
-            if (k >= 1) flush_block(k - 1);
-            if (k + 1 < n_blocks) {
-                hash_block(k + 1);
-                if (k + 2 < n_blocks) load_block(k + 2);
+    // One hand-over: the inserter links block k; the feeders write out block k - 1, hash block k + 1 (register set NEXT_) and
+    // ask for block k + 4 into the set that has just become free.  It concerns LDS only: __syncthreads() would also drain
+    // the feeders' input loads and link stores.  The two roles run their own loops, both to the next multiple of three
+    // hand-overs (blocks that do not exist hash to the no-trigram bucket and are never inserted or written out).
+#define ZWZ_LINKS_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    const uint32_t n_trips = (n_blocks + 2u) / 3u * 3u;
+    if (wave == 0) {
+        for (uint32_t k = 0; k < n_trips; k++) {
+            if (k < n_blocks) {
+                insert_block(k);
             }
+            ZWZ_LINKS_HANDOVER();
         }
-        // the hand-over concerns LDS only: __syncthreads() would also drain the feeder's input loads and link stores,
-        // putting a block's HBM latency back on the critical path of every hand-over
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+#define ZWZ_LINKS_TRIP(K_, NEXT_)                                                                  \
+        if ((K_) == 0u) pad_stores(kStoreOps); else if ((K_) <= n_blocks) flush_block((K_) - 1u);  \
+        hash_block((K_) + 1u, NEXT_{});                                                            \
+        load_block((K_) + 4u, NEXT_{});                                                            \
+        ZWZ_LINKS_HANDOVER();
+        for (uint32_t k = 0; k < n_trips; k += 3u) {
+            ZWZ_LINKS_TRIP(k, Slot1)
+            ZWZ_LINKS_TRIP(k + 1u, Slot2)
+            ZWZ_LINKS_TRIP(k + 2u, Slot0)
+        }
+#undef ZWZ_LINKS_TRIP
     }
+#undef ZWZ_LINKS_HANDOVER
     if (wave >= 1) {
-        flush_block(n_blocks - 1);
+        if (n_trips == n_blocks) flush_block(n_blocks - 1);   // (else the trip after the last block has written it out)
         for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
         if (lane == 0) {                                // lz_match picks its work order by it
-            if (kFeeders > 1) atomicAdd(&link_stat[chunk], linked); else link_stat[chunk] = linked;
+            atomicAdd(&link_stat[chunk], linked);
         }
     }
 }
@@ -2102,8 +1861,7 @@ hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
 }
 
 hipError_t configure_kernels() {
-    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
-    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksXLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
     return hipSuccess;
@@ -2112,8 +1870,7 @@ hipError_t configure_kernels() {
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    if (a.links_xchg) hipLaunchKernelGGL(lz_links_kernel<true>, dim3(a.n), dim3(kLinksXThreads), kLinksXLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
-    else hipLaunchKernelGGL(lz_links_kernel<false>, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat);

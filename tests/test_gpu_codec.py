@@ -113,23 +113,6 @@ def test_deflate_fuzz_large_and_mixed(codec, oracle):
     assert not wrong, wrong[:10]
 
 
-def test_deflate_links_fallback_flavour(zwz, oracle, monkeypatch):
-    """lz_links has two flavours: a context takes the exchange one where the device passes the
-    ordering probe, the read/write/read-back one otherwise or under ZWZ_LINKS=pair.  The other tests run the default;
-    this one pins the fallback to the same bytes."""
-    monkeypatch.setenv("ZWZ_LINKS", "pair")
-    c = zwz.Codec(0, 256)
-    try:
-        kinds = [k for k in corpus.KINDS if k != "lz"]
-        chunks = [corpus.make(k, 41000 + i, n) for i, (k, n) in enumerate((k, n) for k in kinds for n in (1, 700, 2049, 30011, 65535))]
-        chunks += [bytes(65535), b"ab" * 32767, corpus.low_entropy(5, 65535, k=2)]
-        got = c.deflate_chunks(chunks)
-        bad = [(i, len(x)) for i, (x, g) in enumerate(zip(chunks, got)) if g != oracle.payload(x)]
-        assert not bad, bad[:10]
-    finally:
-        c.close()
-
-
 def test_md5_files_dev_matches_hashlib(codec):
     """GPU MD5 of files laid out as 65 535-byte chunks in 65 536-byte slots, against hashlib:
     every padding case (length mod 64 around 55/56/63/0), empty files, the empty trailing chunk of exact multiples,
