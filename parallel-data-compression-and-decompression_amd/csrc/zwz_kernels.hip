@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         if (n_steps >= 6u) {
             // steps s, s+1 issued; bucket addresses of s+2, s+3 at hand; then three steps a trip: read the address of step t+2,
             // exchange for step t, write the link of step t-2 into its slot.  Three LDS operations a step, in order, so "the
-            // exchange of t-2 is back" (and with it the address of t, which is older) is lgkmcnt(5).  Deeper pipelining buys
-            // nothing: the exchange itself retires one lane a cycle, 64 cycles a step, and that is the kernel's time.
+            // exchange of t-2 is back" (and with it the address of t, which is older) is lgkmcnt(5).  The wave issues an
+            // instruction every ~9 cycles and that is the step's time, so the loop is unrolled to six steps a trip.
             uint32_t g0, g1, g2, q0, q1, q2, p1 = p0 + 64u, p2 = p0 + 128u, t0, t1;
             asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
                          "s_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1), "=&v"(g2), "=&v"(g0) : "v"(base) : "memory");
@@ -217,14 +217,28 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 "ds_write_b32 %[base], %[" QR "] offset:" ROFF "\n\t"                                \
                 "v_add_u32 %[" RPOS "], 0xc0, %[" RPOS "]\n\t"
             asm volatile(
-                "1:\n\t"
+                "s_cmp_lt_u32 %[left], 6\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "1:\n\t"                                                       /* six steps a trip while six are left ... */
                 ZWZ_XSTEP("g1", "1024", "g2", "q2", "p2", "q0", "p0", "0")       /* issue s+2, retire s */
                 ZWZ_XSTEP("g2", "1280", "g0", "q0", "p0", "q1", "p1", "256")     /* issue s+3, retire s+1 */
                 ZWZ_XSTEP("g0", "1536", "g1", "q1", "p1", "q2", "p2", "512")     /* issue s+4, retire s+2 */
+                ZWZ_XSTEP("g1", "1792", "g2", "q2", "p2", "q0", "p0", "768")
+                ZWZ_XSTEP("g2", "2048", "g0", "q0", "p0", "q1", "p1", "1024")
+                ZWZ_XSTEP("g0", "2304", "g1", "q1", "p1", "q2", "p2", "1280")
+                "v_add_u32 %[base], 0x600, %[base]\n\t"
+                "s_sub_u32 %[left], %[left], 6\n\t"
+                "s_cmp_gt_u32 %[left], 5\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "2:\n\t"                                                       /* ... then three (the stream of operations stays uniform) */
+                "s_cmp_lt_u32 %[left], 3\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                ZWZ_XSTEP("g1", "1024", "g2", "q2", "p2", "q0", "p0", "0")
+                ZWZ_XSTEP("g2", "1280", "g0", "q0", "p0", "q1", "p1", "256")
+                ZWZ_XSTEP("g0", "1536", "g1", "q1", "p1", "q2", "p2", "512")
                 "v_add_u32 %[base], 0x300, %[base]\n\t"
                 "s_sub_u32 %[left], %[left], 3\n\t"
-                "s_cmp_gt_u32 %[left], 2\n\t"
-                "s_cbranch_scc1 1b\n\t"
+                "3:\n\t"
                 "s_waitcnt lgkmcnt(0)"
                 : [g0] "+v"(g0), [g1] "+v"(g1), [g2] "+v"(g2), [q0] "+v"(q0), [q1] "+v"(q1), [q2] "+v"(q2),
                   [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [base] "+v"(base), [left] "+s"(left)
