@@ -1219,17 +1219,30 @@ static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpo
 // over the input for the checksum (v_dot4 sums four bytes per instruction; skipped when the cap cuts
 // the checksum off), one pass that writes whole output dwords straight to HBM, each from one unaligned
 // 4-byte read of the input except the handful of dwords that touch a header.
+// (lane b of every wave holds block b's byte range: the caller read it alongside the chunk's other metadata, so that the
+// copy is two HBM round trips -- metadata, data -- and not five dependent ones; one workgroup per CU has nothing to hide them behind)
 static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __restrict__ data, uint32_t L, uint32_t n_blocks,
-                                                           const BlockInfo* __restrict__ bi, uint32_t* __restrict__ gout,
+                                                           uint32_t lane_start, uint32_t lane_end, uint32_t* __restrict__ gout,
                                                            uint32_t* __restrict__ out_len_slot) {
     __shared__ uint32_t s_hb[kMaxBlocks + 1], s_st[kMaxBlocks + 1];   // stream offset of each block header; its first input byte
     __shared__ uint32_t s_a[kEncodeThreads / 64], s_adler_be;
     __shared__ unsigned long long s_b[kEncodeThreads / 64];
     const uint32_t tid = threadIdx.x;
+    static_assert(kMaxBlocks == 5, "block ranges are passed in lanes 0..4");
+    const uint32_t bs[kMaxBlocks] = {(uint32_t)__builtin_amdgcn_readlane((int)lane_start, 0), (uint32_t)__builtin_amdgcn_readlane((int)lane_start, 1),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)lane_start, 2), (uint32_t)__builtin_amdgcn_readlane((int)lane_start, 3),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)lane_start, 4)};
+    const uint32_t be[kMaxBlocks] = {(uint32_t)__builtin_amdgcn_readlane((int)lane_end, 0), (uint32_t)__builtin_amdgcn_readlane((int)lane_end, 1),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)lane_end, 2), (uint32_t)__builtin_amdgcn_readlane((int)lane_end, 3),
+                                     (uint32_t)__builtin_amdgcn_readlane((int)lane_end, 4)};
     if (tid == 0) {
         uint32_t hb = 2;
-        for (uint32_t b = 0; b < n_blocks; b++) { s_hb[b] = hb; s_st[b] = bi[b].start; hb += 5u + (bi[b].end - bi[b].start); }
-        for (uint32_t b = n_blocks; b <= kMaxBlocks; b++) { s_hb[b] = hb; s_st[b] = L; }   // s_hb[n_blocks] = where the Adler-32 goes
+#pragma unroll
+        for (uint32_t b = 0; b < kMaxBlocks; b++) {
+            if (b < n_blocks) { s_hb[b] = hb; s_st[b] = bs[b]; hb += 5u + (be[b] - bs[b]); }
+            else { s_hb[b] = hb; s_st[b] = L; }
+        }
+        s_hb[kMaxBlocks] = hb; s_st[kMaxBlocks] = L;                   // s_hb[n_blocks] = where the Adler-32 goes
     }
     const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
     __syncthreads();
@@ -1277,30 +1290,42 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
         if (off < 5u) { const uint32_t f = (len & 0xffffu) | ((~len & 0xffffu) << 16); return (f >> (8u * (off - 1u))) & 0xffu; }
         return data[s_st[b] + off - 5u];
     };
-    // 16 output dwords per thread, every interior dword's two input words in flight before the first is used
-    // (one dword per trip waited out sixteen HBM round trips in a row once the checksum pass no longer warmed L2)
-    const uint32_t n_dw = (n_out + 3u) >> 2;
-    uint32_t q0[16], q1[16], sh[16]; bool fast[16];
+    // Four 16-byte output vectors per thread, each from one 16-byte and one 4-byte read of the input (any dword alignment)
+    // unless it touches a header or the trailer; all reads in flight before the first is used.  (Dword by dword -- two
+    // reads and a store per four bytes -- the copy ran at 3.5 TB/s of traffic; the memory pipeline counts instructions.)
+    const uint32_t n_v = (n_out + 15u) >> 4;
+    uint4 qa[4]; uint32_t qb[4], sh[4]; bool fast[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t o = (tid + u * kEncodeThreads) * 4u;
+    for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t o = (tid + u * kEncodeThreads) * 16u;
         uint32_t b = block_at(o);
         if (b >= n_blocks) b = n_blocks - 1u;
         const uint32_t lo = s_hb[b] + 5u, hi = s_hb[b + 1];
-        fast[u] = (o >> 2) < n_dw && o >= lo && o + 4u <= hi && hi <= h_end;
+        fast[u] = o + 16u <= n_out && o >= lo && o + 16u <= hi && hi <= h_end;
         const uint32_t p = fast[u] ? s_st[b] + (o - lo) : 0u;
         sh[u] = p & 3u;
-        q0[u] = fast[u] ? d32[p >> 2] : 0u;
-        q1[u] = fast[u] && sh[u] ? d32[(p >> 2) + 1] : 0u;
+        const uint32_t* src = d32 + (p >> 2);
+        qa[u] = fast[u] ? make_uint4(src[0], src[1], src[2], src[3]) : make_uint4(0, 0, 0, 0);
+        qb[u] = fast[u] && sh[u] ? src[4] : 0u;          // (the slot is readable to L rounded up to 16: only touched when needed)
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t o4 = tid + u * kEncodeThreads, o = o4 * 4u;
-        if (o4 >= n_dw) continue;
-        uint32_t v;
-        if (fast[u]) v = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh[u]);
-        else v = byte_at(o) | byte_at(o + 1u) << 8 | byte_at(o + 2u) << 16 | byte_at(o + 3u) << 24;
-        gout[o4] = v;
+    for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t ov = tid + u * kEncodeThreads, o = ov * 16u;
+        if (ov >= n_v) continue;
+        uint4 v;
+        if (fast[u]) {
+            v = make_uint4(__builtin_amdgcn_alignbyte(qa[u].y, qa[u].x, sh[u]), __builtin_amdgcn_alignbyte(qa[u].z, qa[u].y, sh[u]),
+                           __builtin_amdgcn_alignbyte(qa[u].w, qa[u].z, sh[u]), __builtin_amdgcn_alignbyte(qb[u], qa[u].w, sh[u]));
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t x = o + 4u * j;
+                w[j] = byte_at(x) | byte_at(x + 1u) << 8 | byte_at(x + 2u) << 16 | byte_at(x + 3u) << 24;
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        reinterpret_cast<uint4*>(gout)[ov] = v;
     }
 }
 
@@ -1335,11 +1360,12 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
 
-    {   // wave-uniform: are all blocks stored?
-        bool all_stored = ci.n_blocks > 0;
-        for (uint32_t b = 0; b < ci.n_blocks; b++) all_stored = all_stored && bo[b].type == kStored;
+    {   // wave-uniform: are all blocks stored?  Lane b looks at block b; these loads do not wait for ci.
+        const uint32_t lb = lane_id() < kMaxBlocks ? lane_id() : 0u;
+        const uint32_t my_type = bo[lb].type, my_start = bi[lb].start, my_end = bi[lb].end;
+        const bool all_stored = ci.n_blocks > 0 && __builtin_amdgcn_ballot_w64(lane_id() < ci.n_blocks && my_type != kStored) == 0;
         if (all_stored) {
-            encode_stored_chunk(data, L, ci.n_blocks, bi, reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
+            encode_stored_chunk(data, L, ci.n_blocks, my_start, my_end, reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
             return;
         }
     }
