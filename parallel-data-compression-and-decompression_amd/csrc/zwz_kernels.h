@@ -11,7 +11,7 @@ namespace zwz {
 // Per-chunk strides of the intermediates (elements).  Everything is indexed [chunk][position].
 constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
 constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
-constexpr uint32_t kLinksThreads = 320;                            // one inserter wave + four feeder waves per chunk
+constexpr uint32_t kLinksThreads = 576;                            // one inserter wave + eight feeder waves per chunk
 constexpr uint32_t kLinksLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // 32-bit head table + spare slot + two bucket-address/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;

@@ -103,8 +103,6 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     const uint32_t Lr = (L + 15u) & ~15u;                                    // the slot is readable this far
     const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
 
-    uint4* h4 = reinterpret_cast<uint4*>(head);
-    for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) link_stat[chunk] = 0;       // the feeder waves add their counts at the end
 
     // ---- feeder: input bytes -> registers (asked for hand-overs ahead, see the main loop) -> bucket addresses in LDS;
@@ -120,9 +118,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     // over links that are written later (pad_stores).  The sets must also stay where they are while a load is in flight:
     // they only ever pass through unconditional asm statements ("+v"), in loops of their own.
     constexpr uint32_t kAhead = 3;
-    static_assert(kPer == 8u, "the feeder below is written for eight positions a lane: an 8-byte and a 4-byte load, one 16-byte link store");
-    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-    struct InSet { v2u c; uint32_t t; };               // input bytes [o, o + 8) and [o + 8, o + 12) of a lane's share
+    static_assert(kPer == 4u, "the feeder below is written for four positions a lane: two 4-byte loads, one 8-byte link store");
+    struct InSet { uint32_t c, t; };                   // input bytes [o, o + 4) and [o + 4, o + 8) of a lane's share
     InSet in_ring[kAhead];
 #pragma unroll
     for (uint32_t r = 0; r < kAhead; r++) { in_ring[r].c = 0; in_ring[r].t = 0; }
@@ -130,12 +127,12 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     constexpr uint32_t kStoreOps = 1u;                                          // ... and of a flush_block
     constexpr uint32_t kWait = 2u * (kLoadOps + kStoreOps) + kStoreOps;         // operations younger than the awaited set: two whole trips and this trip's store
     const uint32_t fpos = (wave - 1u) * (kLinksBlock / kFeeders) + lane * kPer;   // this lane's share within a block (feeder waves)
-    auto load_block = [&](uint32_t k, auto slot) { // input bytes [2048 k + fpos, + 12) -> register set `slot` (= k mod kAhead)
+    auto load_block = [&](uint32_t k, auto slot) { // input bytes [2048 k + fpos, + 8) -> register set `slot` (= k mod kAhead)
         InSet& S = in_ring[decltype(slot)::value];
         const uint32_t o = k * kLinksBlock + fpos;
-        const uint8_t* pa = data + (o + 8u <= Lr ? o : 0u);
-        const uint8_t* pt = data + (o + 12u <= Lr ? o + 8u : 0u);
-        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
+        const uint8_t* pa = data + (o + 4u <= Lr ? o : 0u);
+        const uint8_t* pt = data + (o + 8u <= Lr ? o + 4u : 0u);
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
     };
     auto pad_stores = [&](uint32_t n) {            // n stores with no effect: zeros over this lane's first link of block 0, before its flush_block writes it
         for (uint32_t i = 0; i < n; i++) asm volatile("global_store_short %0, %1, off" :: "v"(lk + fpos), "v"(0u) : "memory");
@@ -143,42 +140,34 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     typedef __attribute__((address_space(3))) uint8_t* lds_byte_ptr;
     const uint32_t head_base = (uint32_t)(uintptr_t)(lds_byte_ptr) reinterpret_cast<uint8_t*>(head);   // 0: this kernel has no static LDS
     uint32_t* hbuf32 = reinterpret_cast<uint32_t*>(hbuf);                       // 32-bit entries: bucket address in, link out
-    auto hash_block = [&](uint32_t k, auto slot) { // bucket addresses of positions [2048 k + fpos, + 8) from the loaded input
+    auto hash_block = [&](uint32_t k, auto slot) { // bucket addresses of positions [2048 k + fpos, + 4) from the loaded input
         InSet& S = in_ring[decltype(slot)::value];
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.c), "+v"(S.t) : "n"(kWait) : "memory");
-        const uint32_t in_w[3] = {S.c.x, S.c.y, S.t};
+        const uint32_t in_w[2] = {S.c, S.t};
         const uint32_t o = k * kLinksBlock + fpos;
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
         uint32_t e[kPer];
 #pragma unroll
         for (uint32_t i = 0; i < kPer; i++) {
-            const uint32_t x = (i & 3u) ? __builtin_amdgcn_alignbyte(in_w[(i >> 2) + 1], in_w[i >> 2], i & 3u) : in_w[i >> 2];
+            const uint32_t x = i ? __builtin_amdgcn_alignbyte(in_w[1], in_w[0], i) : in_w[0];
             uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
             if (i >= n_ok) h = kLinksNoHash;
             e[i] = 4u * h + head_base;                 // the bucket's LDS byte address
         }
-        uint4* dst = reinterpret_cast<uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);
-        dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
-        dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+        *reinterpret_cast<uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos) = make_uint4(e[0], e[1], e[2], e[3]);
     };
     uint32_t linked = 0;                               // feeder: positions of this lane with a chain predecessor
     auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
         const uint32_t o = k * kLinksBlock + fpos;
-        const uint4* src = reinterpret_cast<const uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;
-        const uint4 lo = src[0], hi = src[1];          // 32-bit slots, the link in each one's low half
-        uint4 v = make_uint4((lo.x & 0xffffu) | lo.y << 16, (lo.z & 0xffffu) | lo.w << 16, (hi.x & 0xffffu) | hi.y << 16, (hi.z & 0xffffu) | hi.w << 16);
+        const uint4 w = *reinterpret_cast<const uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);   // 32-bit slots, the link in each one's low half
+        uint2 v = make_uint2((w.x & 0xffffu) | w.y << 16, (w.z & 0xffffu) | w.w << 16);
         if (n_ok < kPer) {                             // rare: the chunk's last positions
-            uint32_t e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-                if (2u * q >= n_ok) e[q] = 0; else if (2u * q + 1u >= n_ok) e[q] &= 0xffffu;
-            }
-            v = make_uint4(e[0], e[1], e[2], e[3]);
+            if (n_ok == 0u) v.x = 0; else if (n_ok == 1u) v.x &= 0xffffu;
+            if (n_ok <= 2u) v.y = 0; else if (n_ok == 3u) v.y &= 0xffffu;
         }
-        *reinterpret_cast<uint4*>(lk + o) = v;
-        linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0)
-                + (uint32_t)((v.z & 0xffffu) != 0) + (uint32_t)((v.z >> 16) != 0) + (uint32_t)((v.w & 0xffffu) != 0) + (uint32_t)((v.w >> 16) != 0);
+        *reinterpret_cast<uint2*>(lk + o) = v;
+        linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0);
     };
 
     // ---- inserter
@@ -198,7 +187,163 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             asm volatile("ds_write_b32 %0, %1" :: "v"(slot), "v"(prev) : "memory");
         };
         uint32_t s = 0;
-        if (n_steps >= 6u) {
+        if (n_steps == kLinksBlock / 64u) {
+            // A whole block (all but the last of a short chunk), straight-line: the wave issues an instruction every ~9 cycles
+            // and that is the step's time, so steps go in PAIRS -- one ds_read2 for two steps' bucket addresses, two
+            // exchanges, one ds_write2 for two steps' links: 8 instructions for 128 positions, no loop, no address
+            // arithmetic (v119..v126 = base + 1024 j; a pair's slots are a base plus constant offsets).  Three register sets
+            // take turns, in named registers -- a ds_read2 fills a register pair whose halves the exchanges use one by one,
+            // which operand constraints cannot express.  Per pair: read the addresses of pair i+1, exchange pair i, write
+            // the links of pair i-2 (with i-1 an exchange had one pair's time to come back and the loop ran at its
+            // latency); four LDS operations in a fixed order, so "the addresses of pair i are here" is lgkmcnt(4) and "the
+            // exchanges of pair i-2 are back" lgkmcnt(8) (dummy reads stand in for the writes the first two pairs lack).
+            asm volatile(
+                "v_add_u32 v119, 0x400, %[base]\n\t"
+                "v_add_u32 v120, 0x800, %[base]\n\t"
+                "v_add_u32 v121, 0xc00, %[base]\n\t"
+                "v_add_u32 v122, 0x1000, %[base]\n\t"
+                "v_add_u32 v123, 0x1400, %[base]\n\t"
+                "v_add_u32 v124, 0x1800, %[base]\n\t"
+                "v_add_u32 v125, 0x1c00, %[base]\n\t"
+                "v_add_u32 v126, 0x2000, %[base]\n\t"
+                "v_mov_b32 v112, %[p0]\n\t"
+                "v_add_u32 v113, 0x40, %[p0]\n\t"
+                "v_add_u32 v114, 0x80, %[p0]\n\t"
+                "v_add_u32 v115, 0xc0, %[p0]\n\t"
+                "v_add_u32 v116, 0x100, %[p0]\n\t"
+                "v_add_u32 v117, 0x140, %[p0]\n\t"
+                "ds_read2_b32 v[100:101], %[base] offset1:64\n\t"
+                "ds_read2_b32 v[102:103], %[base] offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "ds_read_b32 v118, %[base]\n\t"
+                "v_add_u32 v112, 0x180, v112\n\t"
+                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_read2_b32 v[104:105], v119 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
+                "ds_read_b32 v118, %[base]\n\t"
+                "v_add_u32 v114, 0x180, v114\n\t"
+                "v_add_u32 v115, 0x180, v115\n\t"
+                "ds_read2_b32 v[100:101], v119 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 %[base], v106, v107 offset1:64\n\t"
+                "v_add_u32 v116, 0x180, v116\n\t"
+                "v_add_u32 v117, 0x180, v117\n\t"
+                "ds_read2_b32 v[102:103], v120 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 %[base], v108, v109 offset0:128 offset1:192\n\t"
+                "v_add_u32 v112, 0x180, v112\n\t"
+                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_read2_b32 v[104:105], v120 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v119, v110, v111 offset1:64\n\t"
+                "v_add_u32 v114, 0x180, v114\n\t"
+                "v_add_u32 v115, 0x180, v115\n\t"
+                "ds_read2_b32 v[100:101], v121 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v119, v106, v107 offset0:128 offset1:192\n\t"
+                "v_add_u32 v116, 0x180, v116\n\t"
+                "v_add_u32 v117, 0x180, v117\n\t"
+                "ds_read2_b32 v[102:103], v121 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v120, v108, v109 offset1:64\n\t"
+                "v_add_u32 v112, 0x180, v112\n\t"
+                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_read2_b32 v[104:105], v122 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v120, v110, v111 offset0:128 offset1:192\n\t"
+                "v_add_u32 v114, 0x180, v114\n\t"
+                "v_add_u32 v115, 0x180, v115\n\t"
+                "ds_read2_b32 v[100:101], v122 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v121, v106, v107 offset1:64\n\t"
+                "v_add_u32 v116, 0x180, v116\n\t"
+                "v_add_u32 v117, 0x180, v117\n\t"
+                "ds_read2_b32 v[102:103], v123 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v121, v108, v109 offset0:128 offset1:192\n\t"
+                "v_add_u32 v112, 0x180, v112\n\t"
+                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_read2_b32 v[104:105], v123 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v122, v110, v111 offset1:64\n\t"
+                "v_add_u32 v114, 0x180, v114\n\t"
+                "v_add_u32 v115, 0x180, v115\n\t"
+                "ds_read2_b32 v[100:101], v124 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v122, v106, v107 offset0:128 offset1:192\n\t"
+                "v_add_u32 v116, 0x180, v116\n\t"
+                "v_add_u32 v117, 0x180, v117\n\t"
+                "ds_read2_b32 v[102:103], v124 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v123, v108, v109 offset1:64\n\t"
+                "v_add_u32 v112, 0x180, v112\n\t"
+                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_read2_b32 v[104:105], v125 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v123, v110, v111 offset0:128 offset1:192\n\t"
+                "ds_read2_b32 v[100:101], v125 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v124, v106, v107 offset1:64\n\t"
+                "ds_read2_b32 v[102:103], v126 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v124, v108, v109 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(5)\n\t"
+                "ds_write2_b32 v125, v110, v111 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "ds_write2_b32 v125, v106, v107 offset0:128 offset1:192\n\t"
+                "s_nop 0"
+                :
+                : [base] "v"(base), [p0] "v"(p0)
+                : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
+                  "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+            s = n_steps;
+        } else if (n_steps >= 6u) {
             // steps s, s+1 issued; bucket addresses of s+2, s+3 at hand; then three steps a trip: read the address of step t+2,
             // exchange for step t, write the link of step t-2 into its slot.  Three LDS operations a step, in order, so "the
             // exchange of t-2 is back" (and with it the address of t, which is older) is lgkmcnt(5).  The wave issues an
@@ -258,12 +403,17 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     // block k + 2 asked for one hand-over ahead of their use every hand-over waited for them (4.8 of the kernel's 5.4 ms
     // with the inserter switched off).  Three register sets take turns, so a request has three hand-overs to land.
     using Slot0 = std::integral_constant<uint32_t, 0>; using Slot1 = std::integral_constant<uint32_t, 1>; using Slot2 = std::integral_constant<uint32_t, 2>;
-    __syncthreads();
-    if (wave >= 1) {
+    if (wave >= 1) {                                // the first requests go out before the table is cleared: one round trip less per chunk
         load_block(0, Slot0{});
         load_block(1, Slot1{});
         load_block(2, Slot2{});
         pad_stores(3u * kStoreOps);                 // (the counted wait assumes two earlier trips)
+    }
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(head);
+        for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (wave >= 1) {
         hash_block(0, Slot0{});
         load_block(3, Slot0{});
     }
@@ -275,6 +425,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 #define ZWZ_LINKS_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     const uint32_t n_trips = (n_blocks + 2u) / 3u * 3u;
     if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);              // the inserter shares its SIMD with two feeder waves and is the critical path
         for (uint32_t k = 0; k < n_trips; k++) {
             if (k < n_blocks) {
                 insert_block(k);
