@@ -718,7 +718,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             uint32_t nl = 0;                                                               // wave-uniform
             auto drain = [&]() {
                 // The list is refined in place before it is searched, 64 entries a trip with every lane busy: an entry whose
-                // first two candidates both differ from it in the trigram and have no third behind them cannot match (the
+                // first two candidates both differ from it in the trigram's middle byte and have no third behind them cannot match (the
                 // walk would end on them with nothing found) -- on random bytes that is three entries in four, at a sixth
                 // of the cost of a search trip.  Survivors are packed to the front (a trip reads its entries before it writes).
                 uint32_t ns = 0;
@@ -726,13 +726,13 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     const bool valid = i < nl;
                     const uint32_t q = valid ? (uint32_t)wl[i] : 0u, p = ts + q, pi = p - org;
                     const uint32_t floor1 = max(p + 1u, kMaxDist + 1u) - kMaxDist;               // a link >= this is a candidate in range
-                    const uint32_t scan = load_u32(sdata, pi) & 0xffffffu;
+                    const uint32_t scan = sdata[pi + 1u];                                         // (one byte again: see the screening pass)
                     const uint32_t l1 = slink[pi];
                     const uint32_t li1 = valid ? l1 - org : pi;                                   // listed: its first candidate is in range
-                    const uint32_t l2 = slink[li1], cw1 = load_u32(sdata, li1) & 0xffffffu;
+                    const uint32_t l2 = slink[li1], cw1 = sdata[li1 + 1u];
                     const bool in2 = l2 >= floor1;
                     const uint32_t li2 = in2 ? l2 - org : pi;
-                    const uint32_t l3 = slink[li2], cw2 = load_u32(sdata, li2) & 0xffffffu;
+                    const uint32_t l3 = slink[li2], cw2 = sdata[li2 + 1u];
                     uint32_t v = l3 >= floor1 ? scan : cw2;
                     v = in2 ? v : cw1;
                     v = cw1 == scan ? scan : v;
@@ -767,22 +767,25 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) if (p0 + j >= kSlidePos && l1[j] <= kWSize) l1[j] = 0;
                 }
-                uint32_t floor_[5], scan[4], l2[4], cw[4], okm[4];
+                // (the kernel's time is the LDS pipe's: a gather costs ~8 cycles of bank conflicts per dword, so the lone
+                // candidate is tested on ONE byte, the trigram's middle one -- with equal hashes it passes 1 in 64 candidates
+                // that differ, and what it lets through the list's refinement and the search look at in full)
+                uint32_t floor_[5], mid[4], l2[4], cb[4], okm[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 5; j++) floor_[j] = max(p0 + j, kMaxDist + 1u) - kMaxDist;
+                mid[0] = (w0 >> 8) & 0xffu; mid[1] = (w0 >> 16) & 0xffu; mid[2] = w0 >> 24; mid[3] = w1 & 0xffu;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
-                    scan[j] = (j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0) & 0xffffffu;
                     okm[j] = l1[j] >= floor_[j] ? 0xffffffffu : 0u;
                     const uint32_t li = okm[j] ? l1[j] - org : wi + j;                    // a readable stand-in for positions out of play
                     l2[j] = slink[li];
-                    cw[j] = load_u32(sdata, li) & 0xffffffu;
+                    cb[j] = sdata[li + 1u];
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
-                    uint32_t v = l2[j] >= floor_[j + 1] ? scan[j] : cw[j];                // a second candidate, or the only one shares the trigram
+                    uint32_t v = l2[j] >= floor_[j + 1] ? mid[j] : cb[j];                 // a second candidate, or the only one may share the trigram
                     v = okm[j] ? v : 0xffffffffu;
-                    const bool push = v == scan[j];
+                    const bool push = v == mid[j];
                     const uint64_t m = __builtin_amdgcn_ballot_w64(push);
                     if (push) wl[nl + rank_in(m)] = (uint16_t)(q0 + j);
                     nl += (uint32_t)__popcll(m);
