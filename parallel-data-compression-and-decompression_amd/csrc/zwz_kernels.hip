@@ -73,8 +73,8 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // refuses to create a context where it does not hold.  (The round's earlier kernel -- 16-bit buckets, head read / write /
 // read-back per step with collision repair -- took 5.8 ms per 50 000 chunks on random bytes and 35.6 ms on text, where
 // most steps hold colliding hashes.)
-// A lone wave issues an instruction every ~6 cycles, so everything but the exchange is kept off the inserter: four feeder
-// waves turn input bytes into the bucket ADDRESSES of the next 2048 positions in an LDS buffer and move the finished links
+// A lone wave issues an instruction every ~6-9 cycles, so everything but the exchange is kept off the inserter: eight feeder
+// waves (four positions a lane a block) turn input bytes into the bucket ADDRESSES of the next 2048 positions in an LDS buffer and move the finished links
 // of the previous 2048 positions out of that buffer to HBM, both as 16-byte vectors; the two roles meet at a barrier
 // every 2048 positions (two buffers alternate).  Positions past the last trigram are sent to bucket 0: they are the last
 // positions of the chunk, nothing reads the table after them, and the feeders zero their links on the way out -- so the
