@@ -80,6 +80,7 @@ int main(int argc, char* argv[]) {
             printf("Compressing folder: %s\n", source_path.c_str());
             if (!record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
             printf("File record saved location: %s\n", record);
+            if (trace) fprintf(stderr, "zwz: file list ready at %.3f s\n", since());
             if (world_size > 1) { FILE* f = fopen((tag + "_list").c_str(), "w"); if (f) { fputs(record, f); fclose(f); } touch(tag + "_list_ready"); }
         } else {   // the reference broadcasts the record path (main.cpp:24-39)
             if (!wait_for(tag + "_list_ready", 600)) { fprintf(stderr, "rank %d: no file list from rank 0\n", world_rank); return 3; }

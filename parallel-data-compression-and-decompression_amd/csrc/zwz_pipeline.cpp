@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +32,9 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include "zwz_api_internal.h"
@@ -45,6 +48,10 @@ using namespace zwz;
 namespace {
 
 bool verbose() { static int v = getenv("ZWZ_VERBOSE") ? 1 : 0; return v != 0; }
+
+// Chunks per staging slice.  A slice costs 2 x 64 KiB of pinned host memory per chunk, twice (double buffering), and pinning is
+// slow (0.2 s for 4096-chunk slices, a quarter of a 2 GB job); 2048 chunks still give every CU eight chunks a launch.
+constexpr uint32_t kSliceChunks = 2048;
 
 bool blank(const std::string& s) {
     return std::all_of(s.begin(), s.end(), [](unsigned char ch) { return std::isspace(ch) != 0; });
@@ -156,6 +163,10 @@ extern "C" {
 
 int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const char* file_record, int rank, int nranks) {
     if (!c || !src_dir || !dst_dir || !file_record || rank < 0 || nranks <= 0) return ZWZ_E_INVALID;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {          // ZWZ_VERBOSE: the pipeline's own timeline
+        if (verbose()) fprintf(stderr, "zwz: [%.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(), what);
+    };
     std::vector<std::string> lines;
     {
         std::ifstream f(file_record);
@@ -168,45 +179,63 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
     if (rank >= non_empty) return ZWZ_OK;   // main.cpp:47-51: this rank has nothing to do and creates no shard
 
     // this rank's files (compression.cpp:35-41); a file that cannot be opened is logged and skipped (:45-48)
-    struct File { std::string rel, full; int fd; uint64_t size; uint32_t first_chunk, nchunks; std::string md5; std::atomic<int>* md5_ready;
+    struct File { std::string rel, full; bool ok; uint64_t size; uint32_t first_chunk, nchunks; std::string md5; std::atomic<int>* md5_ready;
                   int32_t gpu_md5 = -1; };   // index into its slice's GPU digest list, or -1: hashed on the host
     std::vector<File> files;
     uint64_t total_chunks = 0;
-    for (size_t i = (size_t)rank; i < lines.size(); i += (size_t)nranks) {
-        File f;
-        f.rel = lines[i];
-        f.full = (fs::path(src_dir) / f.rel).string();
-        f.fd = open(f.full.c_str(), O_RDONLY);
-        if (f.fd < 0) { fprintf(stderr, "Error opening source file: \"%s\"\n", f.full.c_str()); continue; }
-        struct stat sb;
-        fstat(f.fd, &sb);
-        f.size = (uint64_t)sb.st_size;
-        f.nchunks = (uint32_t)(f.size / ZWZ_CHUNK_SIZE) + 1;   // a short (possibly empty) read ends the file (:52-58)
-        f.first_chunk = (uint32_t)total_chunks;
-        f.md5_ready = nullptr;
-        total_chunks += f.nchunks;
-        files.push_back(std::move(f));
+    mark("file list read");
+    Pool pool(host_threads());
+    {   // Sizes come from stat(), on the pool; a file is opened only by the task that reads it and closed right after.
+        // (Holding every source file open needed one descriptor per file -- 370 k of them in BASELINE's config 4 -- and
+        // grew the descriptor table step by step, each step a synchronize_rcu() in a process the HIP runtime has made
+        // multi-threaded: 80 us per open(), 0.7 s for 8 000 files, more than the rest of the job.  tools/exp/open_hip.cpp)
+        std::vector<File> cand;
+        for (size_t i = (size_t)rank; i < lines.size(); i += (size_t)nranks) {
+            File f;
+            f.rel = lines[i];
+            f.full = (fs::path(src_dir) / f.rel).string();
+            f.ok = false; f.size = 0; f.md5_ready = nullptr;
+            cand.push_back(std::move(f));
+        }
+        Pool::Group stat_group;
+        for (size_t i0 = 0; i0 < cand.size(); i0 += 256)
+            pool.submit(stat_group, [&cand, i0] {
+                for (size_t i = i0; i < std::min(cand.size(), i0 + 256); i++) {
+                    File& f = cand[i];
+                    struct stat sb;
+                    if (stat(f.full.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && access(f.full.c_str(), R_OK) == 0) { f.ok = true; f.size = (uint64_t)sb.st_size; }
+                }
+            });
+        pool.wait(stat_group);
+        for (File& f : cand) {                     // in list order, like the reference's producer
+            if (!f.ok) { fprintf(stderr, "Error opening source file: \"%s\"\n", f.full.c_str()); continue; }
+            f.nchunks = (uint32_t)(f.size / ZWZ_CHUNK_SIZE) + 1;   // a short (possibly empty) read ends the file (:52-58)
+            f.first_chunk = (uint32_t)total_chunks;
+            total_chunks += f.nchunks;
+            files.push_back(std::move(f));
+        }
     }
     if (total_chunks > 0xffffffffull) { set_error("too many chunks"); return ZWZ_E_INVALID; }
+    mark("source files sized");
     std::vector<std::atomic<int>> ready(files.size());
     for (size_t i = 0; i < files.size(); i++) { ready[i].store(0); files[i].md5_ready = &ready[i]; }
 
     const std::string out_path = (fs::path(dst_dir) / ("compressed_" + std::to_string(rank) + ".zwz")).string();
-    FILE* dest = fopen(out_path.c_str(), "wb");
-    if (!dest) { for (auto& f : files) close(f.fd); set_error("cannot create %s", out_path.c_str()); return ZWZ_E_IO; }
-    std::vector<char> iobuf(16 << 20);
-    setvbuf(dest, iobuf.data(), _IOFBF, iobuf.size());
+    const int dest = open(out_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (dest < 0) { set_error("cannot create %s", out_path.c_str()); return ZWZ_E_IO; }
 
     HIPCHK(hipSetDevice(c->device));
     const uint32_t T = (uint32_t)total_chunks;
-    const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(4096u, (T + 1) / 2 + 1)));
+    const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
     Slices sl;
+    const double t_alloc0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int rc = make_slices(c, cap, sl);
-    if (rc) { fclose(dest); for (auto& f : files) close(f.fd); return rc; }
+    if (verbose()) fprintf(stderr, "zwz: staging for 2 x %u chunks allocated in %.3f s\n", cap,
+                           std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_alloc0);
+    if (rc) { close(dest); return rc; }
     const uint32_t nslices = (T + cap - 1) / cap;
 
-    Pool pool(host_threads());
-    Pool::Group md5_group, read_group[2];
+    Pool::Group md5_group, read_group[2], write_group;
     // chunk g -> (file, chunk index in file): files are laid out back to back
     auto file_of = [&](uint32_t g) -> uint32_t {
         uint32_t lo = 0, hi = (uint32_t)files.size() - 1;
@@ -218,12 +247,15 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         Md5 m;
         std::vector<uint8_t> buf(1 << 20);
         uint64_t off = 0;
-        for (;;) {
-            ssize_t k = pread(files[fi].fd, buf.data(), buf.size(), (off_t)off);
+        const int fd = open(files[fi].full.c_str(), O_RDONLY);
+        if (fd < 0) io_error.store(1);
+        for (; fd >= 0;) {
+            ssize_t k = pread(fd, buf.data(), buf.size(), (off_t)off);
             if (k < 0 && errno == EINTR) continue;
             if (k <= 0) break;
             m.update(buf.data(), (size_t)k); off += (uint64_t)k;
         }
+        if (fd >= 0) close(fd);
         char hex[33]; m.hex(hex);
         files[fi].md5 = hex; files[fi].md5_ready->store(1);
     };
@@ -255,14 +287,16 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
                 pool.submit(read_group[b], [&, fi, b, g0, u0, u1, hash_here] {
                     const File& ff = files[fi];
                     Md5 m;
+                    const int fd = open(ff.full.c_str(), O_RDONLY);
+                    if (fd < 0) io_error.store(1);
                     for (uint32_t ci = u0; ci < u1; ci++) {
                         const uint32_t slot = ff.first_chunk + ci - g0;
                         uint8_t* dstp = sl.h_in[b] + (size_t)slot * ZWZ_DEV_STRIDE;
                         const uint64_t off = (uint64_t)ci * ZWZ_CHUNK_SIZE;
                         const size_t want = off < ff.size ? (size_t)std::min<uint64_t>(ZWZ_CHUNK_SIZE, ff.size - off) : 0;
                         size_t got = 0;
-                        while (got < want) {
-                            ssize_t k = pread(ff.fd, dstp + got, want - got, (off_t)(off + got));
+                        while (got < want && fd >= 0) {
+                            ssize_t k = pread(fd, dstp + got, want - got, (off_t)(off + got));
                             if (k < 0 && errno == EINTR) continue;
                             if (k <= 0) break;
                             got += (size_t)k;
@@ -272,6 +306,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
                         sl.h_len[b][slot] = (uint32_t)got;
                         if (hash_here) m.update(dstp, got);
                     }
+                    if (fd >= 0) close(fd);
                     if (hash_here) { char hex[33]; m.hex(hex); files[fi].md5 = hex; files[fi].md5_ready->store(1); }
                 });
             }
@@ -300,61 +335,127 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         HIPCHK(hipEventRecord(sl.done[b], c->stream));
         return ZWZ_OK;
     };
+    // data_writer(), compression.cpp:73-104.  The shard is one file, but every record's place in it is known once the
+    // slice's payload lengths are back: the caller's thread lays the slice out (and waits for the digests it needs),
+    // then the pool writes it, each worker its own run of records with pwritev straight from the pinned output slots
+    // -- a single buffered writer copied every payload twice and was the whole pipeline's pace (1.9 GB/s).
     uint32_t truncated = 0;
-    auto write_records = [&](uint32_t s) {       // data_writer(), compression.cpp:73-104
+    uint64_t out_pos = 0;                        // shard bytes laid out so far
+    std::atomic<int> write_error{0};
+    struct Rec { uint64_t off; uint32_t slot; int32_t path_len, seq, payload; uint8_t last; const std::string* rel; const char* md5; };
+    std::vector<Rec> recs;
+    std::vector<char> hexes;                     // digests that came back from the GPU as 16 raw bytes, as text
+    auto write_records = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        recs.clear(); recs.reserve(g1 - g0);
+        hexes.resize((size_t)cap * 32);          // (sl.n_md5[b] already counts the slice being read into this buffer pair)
         uint32_t fi = file_of(g0);
         for (uint32_t g = g0; g < g1; g++) {
             while (g >= files[fi].first_chunk + files[fi].nchunks) fi++;
             const File& f = files[fi];
-            const uint32_t slot = g - g0;
-            const int32_t seq = (int32_t)(g - f.first_chunk);
-            const uint8_t last = seq + 1 == (int32_t)f.nchunks;
-            const int32_t path_len = (int32_t)f.rel.size(), payload = (int32_t)sl.h_olen[b][slot];
-            const int32_t total = 4 + path_len + 4 + 1 + payload;
-            fwrite(&total, 4, 1, dest);
-            fwrite(&path_len, 4, 1, dest);
-            fwrite(f.rel.data(), 1, (size_t)path_len, dest);
-            fwrite(&seq, 4, 1, dest);
-            fwrite(&last, 1, 1, dest);
-            fwrite(sl.h_out[b] + (size_t)slot * ZWZ_DEV_STRIDE, 1, (size_t)payload, dest);
-            if (payload == (int32_t)ZWZ_CHUNK_SIZE && sl.h_len[b][slot] >= 65510u) truncated++;
-            if (last) {
+            Rec r;
+            r.slot = g - g0; r.seq = (int32_t)(g - f.first_chunk); r.last = r.seq + 1 == (int32_t)f.nchunks;
+            r.path_len = (int32_t)f.rel.size(); r.payload = (int32_t)sl.h_olen[b][r.slot]; r.rel = &f.rel; r.md5 = nullptr;
+            r.off = out_pos;
+            out_pos += 4u + 4u + (uint64_t)r.path_len + 4u + 1u + (uint64_t)r.payload;
+            if (r.payload == (int32_t)ZWZ_CHUNK_SIZE && sl.h_len[b][r.slot] >= 65510u) truncated++;
+            if (r.last) {
                 if (f.gpu_md5 >= 0) {
                     static const char* dig = "0123456789abcdef";
                     const uint8_t* d = sl.h_dig[b] + (size_t)f.gpu_md5 * 16;
-                    char hex[32];
+                    char* hex = hexes.data() + (size_t)f.gpu_md5 * 32;
                     for (int i = 0; i < 16; i++) { hex[2 * i] = dig[d[i] >> 4]; hex[2 * i + 1] = dig[d[i] & 15]; }
-                    fwrite(hex, 1, 32, dest);
+                    r.md5 = hex;
                 } else {
                     while (!f.md5_ready->load()) std::this_thread::yield();
-                    fwrite(f.md5.data(), 1, f.md5.size(), dest);
+                    r.md5 = f.md5.data();          // 32 hex characters (verification.cpp:24-27)
                 }
+                out_pos += 32u;
             }
+            recs.push_back(r);
         }
+        const size_t n = recs.size(), per = std::max<size_t>(64, (n + 2 * host_threads() - 1) / (2 * host_threads()));
+        for (size_t r0 = 0; r0 < n; r0 += per) {
+            const size_t r1 = std::min(n, r0 + per);
+            pool.submit(write_group, [&, b, r0, r1] {
+                std::vector<int32_t> hdr;  hdr.reserve(4 * (r1 - r0));       // total, path_len | seq per record
+                std::vector<struct iovec> iov; iov.reserve(6 * (r1 - r0));
+                for (size_t i = r0; i < r1; i++) {
+                    const Rec& r = recs[i];
+                    hdr.push_back(4 + r.path_len + 4 + 1 + r.payload); hdr.push_back(r.path_len); hdr.push_back(r.seq); hdr.push_back(0);
+                }
+                for (size_t i = r0; i < r1; i++) {
+                    const Rec& r = recs[i];
+                    int32_t* h = hdr.data() + 4 * (i - r0);
+                    iov.push_back({h, 8});
+                    iov.push_back({const_cast<char*>(r.rel->data()), (size_t)r.path_len});
+                    iov.push_back({h + 2, 4});
+                    iov.push_back({const_cast<uint8_t*>(&r.last), 1});
+                    iov.push_back({sl.h_out[b] + (size_t)r.slot * ZWZ_DEV_STRIDE, (size_t)r.payload});
+                    if (r.last) iov.push_back({const_cast<char*>(r.md5), 32});
+                }
+                uint64_t off = recs[r0].off;
+                size_t k = 0;
+                while (k < iov.size()) {                                     // pwritev: at most IOV_MAX pieces a call, and it may stop short
+                    if (iov[k].iov_len == 0) { k++; continue; }
+                    const int cnt = (int)std::min<size_t>(512, iov.size() - k);
+                    ssize_t w = pwritev(dest, iov.data() + k, cnt, (off_t)off);
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w <= 0) { write_error.store(1); return; }
+                    off += (uint64_t)w;
+                    size_t left = (size_t)w;
+                    while (left) {
+                        if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+                        else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
+                    }
+                }
+            });
+        }
+        pool.wait(write_group);                 // the slice's buffers go back to the GPU next
     };
 
+    // (ZWZ_VERBOSE: where the caller's thread spent its time)
+    double t_read = 0, t_gpu = 0, t_write = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    mark("first slice's reads queued");
     if (nslices) start_read(0);
     for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+        double t0 = now();
         pool.wait(read_group[s & 1]);
+        t_read += now() - t0;
         rc = launch_gpu(s);
         if (rc) break;
+        t0 = now();
         if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
+        t_gpu += now() - t0;
         if (s + 1 < nslices) start_read(s + 1);       // its buffers were last used by slice s-1, now complete
+        t0 = now();
         if (s >= 1) write_records(s - 1);
+        t_write += now() - t0;
     }
     if (rc == ZWZ_OK && nslices) {
+        double t0 = now();
         hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
+        t_gpu += now() - t0; t0 = now();
         if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_records(nslices - 1);
+        t_write += now() - t0;
     }
+    if (verbose())
+        fprintf(stderr, "zwz: %u slices of <= %u chunks in %.3f s: waiting for reads %.3f s, for the GPU %.3f s, writing %.3f s\n",
+                nslices, cap, now() - t_begin, t_read, t_gpu, t_write);
+    mark("last slice written");
     pool.wait(read_group[0]); pool.wait(read_group[1]); pool.wait(md5_group);
     (void)hipStreamSynchronize(c->stream);
+    mark("workers and stream idle");
+    const double t_free0 = now();
     free_slices(sl);
-    for (auto& f : files) close(f.fd);
-    if (ferror(dest) && rc == ZWZ_OK) rc = ZWZ_E_IO;
-    if (fclose(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
-    if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed size while it was being read"); rc = ZWZ_E_IO; }
+    if (verbose()) fprintf(stderr, "zwz: staging released in %.3f s\n", now() - t_free0);
+    if (write_error.load() && rc == ZWZ_OK) { set_error("writing %s failed", out_path.c_str()); rc = ZWZ_E_IO; }
+    if (close(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
+    mark("shard closed");
+    if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed or vanished while it was being read"); rc = ZWZ_E_IO; }
     if (truncated && verbose())
         fprintf(stderr, "zwz: %u chunk payload(s) reached the reference's 65535-byte cap (lossy, like the reference)\n", truncated);
     return rc;
@@ -383,11 +484,21 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
         if (fd < 0) { fprintf(stderr, "Error opening file: %s\n", shard.c_str()); continue; }
         struct stat sb;
         fstat(fd, &sb);
-        std::vector<uint8_t> blob((size_t)sb.st_size);
-        size_t got = 0;
-        while (got < blob.size()) { ssize_t k = read(fd, blob.data() + got, blob.size() - got); if (k <= 0) break; got += (size_t)k; }
+        // the shard is mapped, not read: the records are parsed in place and the pool copies payloads from the mapping
+        // straight into the pinned staging slots (a read() into a zero-filled vector was two serial passes over the file)
+        struct Mapped {
+            const uint8_t* p = nullptr; size_t n = 0;
+            ~Mapped() { if (p) munmap(const_cast<uint8_t*>(p), n); }
+            size_t size() const { return n; }
+            const uint8_t& operator[](size_t i) const { return p[i]; }
+        } blob;
+        if (sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); set_error("cannot map %s", shard.c_str()); return ZWZ_E_IO; }
+            blob.p = static_cast<const uint8_t*>(m); blob.n = (size_t)sb.st_size;
+            (void)madvise(m, blob.n, MADV_WILLNEED);
+        }
         close(fd);
-        blob.resize(got);
 
         struct Rec { uint64_t off; uint32_t len; int32_t seq; uint8_t last; };
         struct FileInst { std::string rel; std::vector<Rec> order; std::multimap<int32_t, Rec> pending; int32_t expected = 0; std::string md5; bool finalised = false; };
@@ -434,7 +545,7 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
         std::vector<OutState> outs(insts.size());
         for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
         const uint32_t T = (uint32_t)jobs.size();
-        const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(4096u, (T + 1) / 2 + 1)));
+        const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
         Slices sl;
         rc = make_slices(c, cap, sl);
         if (rc) return rc;
