@@ -380,3 +380,21 @@ def test_one_large_file_like_config5(codec, oracle, tmp_path):
     obad = oracle.decompress_shard(str(want_dir / "compressed_0.zwz"), str(oback))
     assert bad == obad == 1                                             # the random tail is truncated -> MD5 mismatch
     assert open(back / "big.bin", "rb").read() == open(oback / "big.bin", "rb").read()
+
+
+def test_list_names_a_file_that_is_gone(codec, oracle, tmp_path):
+    """compression.cpp:45-48: a listed file that cannot be opened is logged and skipped; the shard holds the others.
+    (The pipeline sizes files with stat() and opens each one only while it is read.)"""
+    src = tmp_path / "src"
+    src.mkdir()
+    names = []
+    for i, n in enumerate((70000, 5, 131070, 0, 3000)):
+        (src / ("f%d.bin" % i)).write_bytes(corpus.make("text" if i % 2 else "random", 61000 + i, n))
+        names.append("f%d.bin" % i)
+    rec = tmp_path / "list.txt"
+    rec.write_text("".join(n + "\n" for n in names[:2] + ["gone.bin"] + names[2:]))
+    got_dir, want_dir = tmp_path / "got", tmp_path / "want"
+    got_dir.mkdir(); want_dir.mkdir()
+    codec.do_compression(str(src), str(got_dir), str(rec), 0, 1)
+    assert oracle.compress_shard(str(src), str(want_dir), str(rec), 0, 1) == 0
+    assert sha(open(got_dir / "compressed_0.zwz", "rb").read()) == sha(open(want_dir / "compressed_0.zwz", "rb").read())
