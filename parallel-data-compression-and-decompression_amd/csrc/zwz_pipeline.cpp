@@ -273,7 +273,6 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
             File& f = files[fi];
             const uint32_t c0 = g - f.first_chunk, c1 = std::min(f.nchunks, c0 + (g1 - g));
             const bool whole = c0 == 0 && c1 == f.nchunks;
-            if (!whole && c0 == 0) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });
             // units of <= 64 chunks so that big files are read by several workers
             for (uint32_t u0 = c0; u0 < c1; u0 += 64) {
                 const uint32_t u1 = std::min(c1, u0 + 64);
@@ -310,11 +309,18 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
                     if (hash_here) { char hex[33]; m.hex(hex); files[fi].md5 = hex; files[fi].md5_ready->store(1); }
                 });
             }
-            if (whole && c1 - c0 > 64) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });   // read in pieces: hash separately
             g += c1 - c0;
         }
     };
-    // a whole file read as ONE unit is hashed by its reader; every other file by hash_whole_file
+    // a whole file read as ONE unit is hashed by its reader (or the GPU); every other file -- cut by a slice boundary, or
+    // read in pieces -- by hash_whole_file.  Those tasks only need the source file, and MD5 is one sequential stream per
+    // file (~0.65 GB/s), so they all go out NOW: submitted when the pipeline reached the file, three 384 MiB files were
+    // hashed one after the other with the record writer waiting for each digest in turn.
+    for (uint32_t fi = 0; fi < (uint32_t)files.size(); fi++) {
+        const File& f = files[fi];
+        const bool whole = f.first_chunk / cap == (f.first_chunk + f.nchunks - 1) / cap;
+        if (!whole || f.nchunks > 64) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });
+    }
     auto launch_gpu = [&](uint32_t s) -> int {
         const int b = (int)(s & 1u);
         const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
@@ -541,7 +547,7 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
         struct Job { uint32_t inst; Rec r; };
         std::vector<Job> jobs;
         for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
-        struct OutState { FILE* f = nullptr; Md5 md5; uint32_t remaining = 0; bool failed = false; };
+        struct OutState { FILE* f = nullptr; int fd = -1; uint64_t written = 0; Md5 md5; uint32_t remaining = 0; bool failed = false; bool deferred = false; };
         std::vector<OutState> outs(insts.size());
         for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
         const uint32_t T = (uint32_t)jobs.size();
@@ -550,7 +556,19 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
         rc = make_slices(c, cap, sl);
         if (rc) return rc;
         const uint32_t nslices = (T + cap - 1) / cap;
-        Pool::Group fill_group[2], write_group;
+        Pool::Group fill_group[2], write_group, md5_group;
+        // MD5 is one sequential stream per file (~0.65 GB/s).  A file decoded within one slice is hashed by the task that
+        // writes it, from the staging buffer; a file that spans slices would hold every slice back for its hash (three
+        // 384 MiB files: 2.1 s, slower than the reference), so it is hashed afterwards, from the file just written, by a
+        // task of its own that runs beside the slices of the files behind it.
+        {
+            uint32_t g = 0;
+            for (uint32_t i = 0; i < insts.size(); i++) {
+                const uint32_t k = (uint32_t)insts[i].order.size();
+                if (k) outs[i].deferred = g / cap != (g + k - 1) / cap;
+                g += k;
+            }
+        }
 
         auto open_out = [&](uint32_t inst) {
             const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
@@ -605,29 +623,91 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
             HIPCHK(hipEventRecord(sl.done[b], c->stream));
             return ZWZ_OK;
         };
-        auto write_slice = [&](uint32_t s) {     // one task per file that has records in this slice
+        // One task per file that has records in this slice -- a file decoded within one slice is written (stdio) and hashed
+        // by it.  A file that spans slices is written with pwritev at offsets laid out here, 128 records a task, and
+        // hashed afterwards from the file (see `deferred` above).
+        auto write_slice = [&](uint32_t s) {
             const int b = (int)(s & 1u);
             const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+            std::vector<uint32_t> finished;          // spanning files whose last record is in this slice
             uint32_t g = g0;
             while (g < g1) {
                 uint32_t e = g;
                 while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
                 const uint32_t inst = jobs[g].inst, a0 = g, a1 = e;
-                pool.submit(write_group, [&, b, g0, inst, a0, a1] {
-                    OutState& o = outs[inst];
-                    if (!o.f && !o.failed) open_out(inst);
-                    for (uint32_t k = a0; k < a1; k++) {
-                        const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
-                        const uint32_t n = sl.h_olen[b][k - g0];
-                        if (o.f) fwrite(src, 1, n, o.f);
-                        o.md5.update(src, n);
+                OutState& os = outs[inst];
+                if (!os.deferred) {
+                    pool.submit(write_group, [&, b, g0, inst, a0, a1] {
+                        OutState& o = outs[inst];
+                        if (!o.f && !o.failed) open_out(inst);
+                        for (uint32_t k = a0; k < a1; k++) {
+                            const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
+                            const uint32_t n = sl.h_olen[b][k - g0];
+                            if (o.f) fwrite(src, 1, n, o.f);
+                            o.md5.update(src, n);
+                        }
+                        o.remaining -= a1 - a0;
+                        if (o.remaining == 0) finish_out(inst);
+                    });
+                } else {
+                    if (os.fd < 0 && !os.failed) {
+                        const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
+                        std::error_code ec;
+                        fs::path dir = fs::path(file_path).parent_path();
+                        if (!dir.empty() && !fs::exists(dir, ec)) fs::create_directories(dir, ec);
+                        os.fd = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+                        if (os.fd < 0) { std::lock_guard<std::mutex> l(log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); os.failed = true; }
                     }
-                    o.remaining -= a1 - a0;
-                    if (o.remaining == 0) finish_out(inst);
-                });
+                    for (uint32_t r0 = a0; r0 < a1 && os.fd >= 0; r0 += 128) {
+                        const uint32_t r1 = std::min(a1, r0 + 128);
+                        const uint64_t off0 = os.written;
+                        uint64_t bytes = 0;
+                        for (uint32_t k = r0; k < r1; k++) bytes += sl.h_olen[b][k - g0];
+                        os.written += bytes;
+                        const int fd = os.fd;
+                        pool.submit(write_group, [&, b, g0, fd, r0, r1, off0] {
+                            std::vector<struct iovec> iov;
+                            for (uint32_t k = r0; k < r1; k++)
+                                if (sl.h_olen[b][k - g0]) iov.push_back({sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE, (size_t)sl.h_olen[b][k - g0]});
+                            uint64_t off = off0;
+                            size_t k = 0;
+                            while (k < iov.size()) {
+                                ssize_t w = pwritev(fd, iov.data() + k, (int)std::min<size_t>(512, iov.size() - k), (off_t)off);
+                                if (w < 0 && errno == EINTR) continue;
+                                if (w <= 0) break;                            // (a short file then fails its MD5 check)
+                                off += (uint64_t)w;
+                                size_t left = (size_t)w;
+                                while (left) {
+                                    if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+                                    else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
+                                }
+                            }
+                        });
+                    }
+                    os.remaining -= a1 - a0;
+                    if (os.remaining == 0) finished.push_back(inst);
+                }
                 g = e;
             }
             pool.wait(write_group);              // the next slice of a file must follow this one
+            for (uint32_t inst : finished) {
+                OutState& o = outs[inst];
+                if (o.fd >= 0) { close(o.fd); o.fd = -1; }
+                pool.submit(md5_group, [&, inst] {
+                    OutState& oo = outs[inst];
+                    const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
+                    const int fd = open(file_path.c_str(), O_RDONLY);
+                    std::vector<uint8_t> buf(1 << 20);
+                    for (uint64_t off = 0; fd >= 0;) {
+                        ssize_t k = pread(fd, buf.data(), buf.size(), (off_t)off);
+                        if (k < 0 && errno == EINTR) continue;
+                        if (k <= 0) break;
+                        oo.md5.update(buf.data(), (size_t)k); off += (uint64_t)k;
+                    }
+                    if (fd >= 0) close(fd);
+                    finish_out(inst);
+                });
+            }
         };
 
         if (nslices) start_fill(0);
@@ -643,7 +723,7 @@ int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int
             hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
             if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_slice(nslices - 1);
         }
-        pool.wait(fill_group[0]); pool.wait(fill_group[1]);
+        pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(md5_group);
         (void)hipStreamSynchronize(c->stream);
         free_slices(sl);
         // instances that never received a decodable record still get created (the reference opens on
