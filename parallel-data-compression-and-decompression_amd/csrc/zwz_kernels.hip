@@ -84,8 +84,8 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 //   * every step / hand-over issues exactly the same operations in the same order, whatever its lanes hold;
 //   * no in-flight register is read, copied or merged before the wait that covers it;
 //   * the loops are entered with nothing in flight (inserter) or a known number of operations in flight (feeders).
-constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the two waves
-constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (see below: any bucket will do)
+constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the inserter and the feeders
+constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (any bucket will do, see above)
 
 __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
     extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 32-bit buckets + 16 spare bytes
     constexpr uint32_t kHeadBytes = 131072u;
-    uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock: hashes in, links out
+    uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock 32-bit entries: bucket addresses in, links out
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t L = in_len[chunk];
     if (L == 0) { if (tid == 0) link_stat[chunk] = 0; return; }
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             // arithmetic (v119..v126 = base + 1024 j; a pair's slots are a base plus constant offsets).  Three register sets
             // take turns, in named registers -- a ds_read2 fills a register pair whose halves the exchanges use one by one,
             // which operand constraints cannot express.  Per pair: read the addresses of pair i+1, exchange pair i, write
-            // the links of pair i-2 (with i-1 an exchange had one pair's time to come back and the loop ran at its
-            // latency); four LDS operations in a fixed order, so "the addresses of pair i are here" is lgkmcnt(4) and "the
+            // the links of pair i-2 (one pair more in flight than strictly needed: it cost nothing and leaves the exchange's
+            // latency off the path); four LDS operations in a fixed order, so "the addresses of pair i are here" is lgkmcnt(4) and "the
             // exchanges of pair i-2 are back" lgkmcnt(8) (dummy reads stand in for the writes the first two pairs lack).
             asm volatile(
                 "v_add_u32 v119, 0x400, %[base]\n\t"
