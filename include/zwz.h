@@ -48,7 +48,7 @@ typedef enum zwz_status {
     ZWZ_OK = 0,
     ZWZ_E_INVALID = -1,   /* bad argument (null pointer, misaligned device slot, size > 65535) */
     ZWZ_E_HIP = -2,       /* a HIP runtime call failed; zwz_last_error() has the text */
-    ZWZ_E_NO_DEVICE = -3, /* no usable gfx950 device */
+    ZWZ_E_NO_DEVICE = -3, /* no usable gfx950 device (none visible, or it fails zwz_ctx_create's check of the LDS exchange order lz_links needs) */
     ZWZ_E_IO = -4,        /* file system error */
     ZWZ_E_NOMEM = -5,
     ZWZ_E_FORMAT = -6     /* malformed .zwz shard */
