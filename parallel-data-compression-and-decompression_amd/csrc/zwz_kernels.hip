@@ -193,10 +193,10 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             // exchanges, one ds_write2 for two steps' links: 8 instructions for 128 positions, no loop, no address
             // arithmetic (v119..v126 = base + 1024 j; a pair's slots are a base plus constant offsets).  Three register sets
             // take turns, in named registers -- a ds_read2 fills a register pair whose halves the exchanges use one by one,
-            // which operand constraints cannot express.  Per pair: read the addresses of pair i+1, exchange pair i, write
-            // the links of pair i-2 (one pair more in flight than strictly needed: it cost nothing and leaves the exchange's
-            // latency off the path); four LDS operations in a fixed order, so "the addresses of pair i are here" is lgkmcnt(4) and "the
-            // exchanges of pair i-2 are back" lgkmcnt(8) (dummy reads stand in for the writes the first two pairs lack).
+            // which operand constraints cannot express.  Per pair: read the addresses of pair i+1, write the links of pair i-2,
+            // exchange pair i; four LDS operations in a fixed order, so one lgkmcnt(4) in front of the write says both "the
+            // addresses of pair i are here" and "the exchanges of pair i-2 are back", with pair i-1's still in flight (dummy
+            // reads stand in for the writes the first two pairs lack): 7 instructions a pair.
             asm volatile(
                 "v_add_u32 v119, 0x400, %[base]\n\t"
                 "v_add_u32 v120, 0x800, %[base]\n\t"
@@ -213,127 +213,113 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 "v_add_u32 v116, 0x100, %[p0]\n\t"
                 "v_add_u32 v117, 0x140, %[p0]\n\t"
                 "ds_read2_b32 v[100:101], %[base] offset1:64\n\t"
-                "ds_read2_b32 v[102:103], %[base] offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
+                "ds_read2_b32 v[102:103], %[base] offset0:128 offset1:192\n\t"
+                "ds_read_b32 v118, %[base]\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "ds_read_b32 v118, %[base]\n\t"
                 "v_add_u32 v112, 0x180, v112\n\t"
                 "v_add_u32 v113, 0x180, v113\n\t"
                 "ds_read2_b32 v[104:105], v119 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_read_b32 v118, %[base]\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "ds_read_b32 v118, %[base]\n\t"
                 "v_add_u32 v114, 0x180, v114\n\t"
                 "v_add_u32 v115, 0x180, v115\n\t"
                 "ds_read2_b32 v[100:101], v119 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 %[base], v106, v107 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
                 "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 %[base], v106, v107 offset1:64\n\t"
                 "v_add_u32 v116, 0x180, v116\n\t"
                 "v_add_u32 v117, 0x180, v117\n\t"
                 "ds_read2_b32 v[102:103], v120 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 %[base], v108, v109 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 %[base], v108, v109 offset0:128 offset1:192\n\t"
                 "v_add_u32 v112, 0x180, v112\n\t"
                 "v_add_u32 v113, 0x180, v113\n\t"
                 "ds_read2_b32 v[104:105], v120 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v119, v110, v111 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v119, v110, v111 offset1:64\n\t"
                 "v_add_u32 v114, 0x180, v114\n\t"
                 "v_add_u32 v115, 0x180, v115\n\t"
                 "ds_read2_b32 v[100:101], v121 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v119, v106, v107 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
                 "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v119, v106, v107 offset0:128 offset1:192\n\t"
                 "v_add_u32 v116, 0x180, v116\n\t"
                 "v_add_u32 v117, 0x180, v117\n\t"
                 "ds_read2_b32 v[102:103], v121 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v120, v108, v109 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v120, v108, v109 offset1:64\n\t"
                 "v_add_u32 v112, 0x180, v112\n\t"
                 "v_add_u32 v113, 0x180, v113\n\t"
                 "ds_read2_b32 v[104:105], v122 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v120, v110, v111 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v120, v110, v111 offset0:128 offset1:192\n\t"
                 "v_add_u32 v114, 0x180, v114\n\t"
                 "v_add_u32 v115, 0x180, v115\n\t"
                 "ds_read2_b32 v[100:101], v122 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v121, v106, v107 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
                 "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v121, v106, v107 offset1:64\n\t"
                 "v_add_u32 v116, 0x180, v116\n\t"
                 "v_add_u32 v117, 0x180, v117\n\t"
                 "ds_read2_b32 v[102:103], v123 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v121, v108, v109 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v121, v108, v109 offset0:128 offset1:192\n\t"
                 "v_add_u32 v112, 0x180, v112\n\t"
                 "v_add_u32 v113, 0x180, v113\n\t"
                 "ds_read2_b32 v[104:105], v123 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v122, v110, v111 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v122, v110, v111 offset1:64\n\t"
                 "v_add_u32 v114, 0x180, v114\n\t"
                 "v_add_u32 v115, 0x180, v115\n\t"
                 "ds_read2_b32 v[100:101], v124 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v122, v106, v107 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
                 "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v122, v106, v107 offset0:128 offset1:192\n\t"
                 "v_add_u32 v116, 0x180, v116\n\t"
                 "v_add_u32 v117, 0x180, v117\n\t"
                 "ds_read2_b32 v[102:103], v124 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v123, v108, v109 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v123, v108, v109 offset1:64\n\t"
                 "v_add_u32 v112, 0x180, v112\n\t"
                 "v_add_u32 v113, 0x180, v113\n\t"
                 "ds_read2_b32 v[104:105], v125 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v123, v110, v111 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v123, v110, v111 offset0:128 offset1:192\n\t"
                 "ds_read2_b32 v[100:101], v125 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v124, v106, v107 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
                 "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v124, v106, v107 offset1:64\n\t"
                 "ds_read2_b32 v[102:103], v126 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_write2_b32 v124, v108, v109 offset0:128 offset1:192\n\t"
                 "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
                 "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(8)\n\t"
-                "ds_write2_b32 v124, v108, v109 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(5)\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
                 "ds_write2_b32 v125, v110, v111 offset1:64\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "ds_write2_b32 v125, v106, v107 offset0:128 offset1:192\n\t"
