@@ -702,14 +702,15 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 448
             uint16_t* wl = s_cnt + wave * kListCap;
             uint32_t nl = 0;                                                               // wave-uniform
-            auto drain = [&]() {
+            auto drain = [&](bool all) {                                 // all: the tile is over; else whole trips only, the rest waits
                 // The list is refined in place before it is searched, 64 entries a trip with every lane busy: an entry whose
                 // first two candidates both differ from it in the trigram's middle byte and have no third behind them cannot match (the
                 // walk would end on them with nothing found) -- on random bytes that is three entries in four, at a sixth
                 // of the cost of a search trip.  Survivors are packed to the front (a trip reads its entries before it writes).
+                const uint32_t n_proc = all ? nl : nl & ~63u;               // (a ragged last trip ran a quarter of its lanes)
                 uint32_t ns = 0;
-                for (uint32_t i = lane; i - lane < nl; i += 64u) {
-                    const bool valid = i < nl;
+                for (uint32_t i = lane; i - lane < n_proc; i += 64u) {
+                    const bool valid = i < n_proc;
                     const uint32_t q = valid ? (uint32_t)wl[i] : 0u, p = ts + q, pi = p - org;
                     const uint32_t floor1 = max(p + 1u, kMaxDist + 1u) - kMaxDist;               // a link >= this is a candidate in range
                     const uint32_t scan = sdata[pi + 1u];                                         // (one byte again: see the screening pass)
@@ -728,7 +729,10 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     ns += (uint32_t)__popcll(m);
                 }
                 for (uint32_t i = lane; i - lane < ns; i += 64u) search_and_store(i < ns ? ts + (uint32_t)wl[i] : ts, i < ns);
-                nl = 0;
+                const uint32_t rem = nl - n_proc;                            // < 64 entries go to the front and wait for company
+                const uint32_t keepq = lane < rem ? (uint32_t)wl[n_proc + lane] : 0u;
+                if (lane < rem) wl[lane] = (uint16_t)keepq;
+                nl = rem;
             };
             // A lane screens four consecutive positions a trip: their links are one 8-byte read, their trigrams come out of
             // two words.  Tests are selects on compare masks -- no flag words, no short-circuit logic (as bool tests and
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             for (uint32_t t4 = 0; t4 < 4u; t4++) {
                 const uint32_t qb = wave * 1024u + t4 * 256u;                              // wave-uniform
                 if (qb >= n_ok) break;
-                if (nl + 256u > kListCap) drain();
+                if (nl + 256u > kListCap) drain(false);
                 const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = p0 - org;            // wi: window index, a multiple of 4
                 const uint2 lk2 = *reinterpret_cast<const uint2*>(slink + wi);
                 const uint32_t w0 = reinterpret_cast<const uint32_t*>(sdata + wi)[0], w1 = reinterpret_cast<const uint32_t*>(sdata + wi)[1];
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     nl += (uint32_t)__popcll(m);
                 }
             }
-            drain();
+            drain(true);
         }
         __syncthreads();
         for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads) {
