@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- compress + decompress throughput of the chunk codec on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch: deflate every 65535-byte chunk of a
-synthetic directory image resident in HBM, then inflate the resulting payloads (also resident).
-Default workload = BASELINE.json configs[1]: 10 000 x 256 KiB incompressible random files
-(50 000 chunks: 4 full + one 4-byte chunk per file).  `value` = raw bytes / (deflate + inflate
-time), whole job over all ranks (max over ranks of the timed region).  Ranks own disjoint files
-(shards partition one-per-rank): weak scaling, no data-path collective.
+One "step" = one pass of the hot path over one batch resident in HBM: deflate every <= 65535-byte chunk of a synthetic
+directory image, then inflate the resulting payloads.  `value` = raw bytes / (deflate + inflate time), whole job over
+all ranks (max over ranks of the timed region).  Ranks own disjoint files (shards partition one-per-rank, SURVEY.md
+section 8e): weak scaling, no data-path collective.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel's (raw + payload) bytes per launch / its mean launch duration,
-                measured with HIP events on the codec's own stream, against the 8 TB/s HBM peak
-  cpu_baseline  the reference binary (oracle/_ref/main, kind "reference") or, if it cannot run on
-                this box, the oracle restatement (kind "port"), timed on a bounded sample
+With no --workload the run covers BOTH headline configurations and prints ONE JSON line:
+  top level   BASELINE configs[1]: 10 000 x 256 KiB incompressible files (50 000 chunks; stored-block path)
+  "text"      BASELINE configs[2]: 10 000 x 256 KiB text-like files (LZ77 + Huffman kernels), same fields
+Other workloads on request: --workload small_files (configs[3]: ~370 000 image-like files, ~2.5 GB) and
+--workload one_file --decompress-only (configs[4] scaled to fit: ONE file, its records split over the ranks).
+
+Every line also carries
+  roofline      dominant kernel's (raw + payload) bytes per launch / its mean launch duration, measured with HIP events on
+                the codec's own stream, against the 8 TB/s HBM peak; plus whole-direction fractions against 8.0 and 6.29 TB/s
+  verified      outside the timed region: every decoded byte compared with the input on the device (not lengths), and
+                >= 512 sampled chunks per workload compared with the CPU oracle (payload bytes and decoded bytes)
+  cpu_baseline  the REFERENCE binary (oracle/_ref/main) on this box's host cores, 1/2/4/8 MPI ranks, on a bounded sample of
+                the same files (same PRNG, same seeds) and on BASELINE configs[0]'s shape (100 x 1 MiB)
+
+`--gpus N` without a launcher starts N ranks itself (fresh child processes, before this process touches the GPU); under a
+launcher (WORLD_SIZE set) a mismatch between --gpus and WORLD_SIZE is an error.
 """
 import argparse
 import importlib
@@ -29,7 +38,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CHUNK, STRIDE = 65535, 65536
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0    # ... 6.29 TB/s measured-achievable
+MPIEXEC = "/opt/conda/bin/mpiexec"
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "main")
 
 
 def parse_args():
@@ -37,109 +49,342 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="random", choices=["random", "text"])
-    ap.add_argument("--files", type=int, default=10000)
+    ap.add_argument("--workload", default="both", choices=["both", "random", "text", "small_files", "one_file"])
+    ap.add_argument("--files", type=int, default=None, help="files per GPU (default 10000; small_files: 370000)")
     ap.add_argument("--file-bytes", type=int, default=262144)
+    ap.add_argument("--one-file-bytes", type=int, default=8 << 30, help="one_file: size of the single file (BASELINE: 64 GiB)")
+    ap.add_argument("--decompress-only", action="store_true", help="time inflate only (one_file: BASELINE configs[4])")
     ap.add_argument("--max-batch", type=int, default=51200)   # whole config-2 batch in one launch per kernel: ~48 GB of workspace, sized for 288 GB of HBM
-    ap.add_argument("--cpu-sample-files", type=int, default=2400)   # ~12-17 s of reference CPU work
+    ap.add_argument("--oracle-sample", type=int, default=512)
+    ap.add_argument("--cpu-sample-files", type=int, default=400)   # x 256 KiB = 105 MB: ~4 s of reference CPU work at 1 rank
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-port", action="store_true", help="time the oracle restatement if the reference binary is absent (labelled kind=port)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks share cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
     return ap.parse_args()
 
 
-def build_batch(torch, dev, workload, n_files, file_bytes, seed):
-    """Device image of n_files files cut the reference's way (compression.cpp:52-64)."""
-    import numpy as np
-    full, tail = divmod(file_bytes, CHUNK)
-    per_file = full + 1                       # a short (possibly empty) read ends the file
-    n = n_files * per_file
-    lens = np.full((n_files, per_file), CHUNK, dtype=np.uint32)
-    lens[:, -1] = tail
-    d_in = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
-    view = d_in.view(n_files, per_file, STRIDE)
-    if workload == "random":
-        g = torch.Generator(device=dev)
-        g.manual_seed(seed)
-        step = 500
-        for f0 in range(0, n_files, step):
-            f1 = min(n_files, f0 + step)
-            r = torch.randint(0, 256, (f1 - f0, file_bytes), dtype=torch.uint8, device=dev, generator=g)
-            for c in range(full):
-                view[f0:f1, c, :CHUNK] = r[:, c * CHUNK:(c + 1) * CHUNK]
-            if tail:
-                view[f0:f1, full, :tail] = r[:, full * CHUNK:]
-    else:
-        import corpus
-        distinct = min(n_files, 256)
-        host = np.zeros((distinct, file_bytes), dtype=np.uint8)
-        for i in range(distinct):
-            host[i] = np.frombuffer(corpus.text_like(seed * 1000 + i, file_bytes), dtype=np.uint8)
-        t = torch.from_numpy(host).to(dev)
-        for f0 in range(0, n_files, distinct):
-            f1 = min(n_files, f0 + distinct)
-            r = t[:f1 - f0]
-            for c in range(full):
-                view[f0:f1, c, :CHUNK] = r[:, c * CHUNK:(c + 1) * CHUNK]
-            if tail:
-                view[f0:f1, full, :tail] = r[:, full * CHUNK:]
-    d_len = torch.from_numpy(lens.reshape(-1).astype(np.int32)).to(dev)
-    d_off = (torch.arange(n, dtype=torch.int64, device=dev) * STRIDE)
-    return d_in, d_off, d_len, n, int(n_files) * int(file_bytes)
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """--gpus N with no launcher around us: start N ranks as children (this process has not touched the GPU) and
+    return the launcher's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
-def cpu_baseline(workload, file_bytes, n_files):
-    """Reference CPU path on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_facts(path):
+    facts = {"cpu_model": None, "logical_cpus": os.cpu_count(), "physical_cores": None, "sockets": None, "filesystem": None}
+    try:
+        model, cores = None, set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        facts["cpu_model"] = model
+        facts["physical_cores"] = len(cores) or None
+        facts["sockets"] = len({p for p, _ in cores}) or None
+    except OSError:
+        pass
+    try:
+        best = ""
+        for line in open("/proc/mounts"):
+            parts = line.split()
+            if len(parts) >= 3 and (path == parts[1] or path.startswith(parts[1].rstrip("/") + "/")) and len(parts[1]) >= len(best):
+                best, facts["filesystem"] = parts[1], parts[2]
+    except OSError:
+        pass
+    try:
+        facts["cpus_allowed"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    return facts
+
+
+def _time_reference(src, work, total_bytes, ranks):
+    """The reference's CLI (README.md:59) as `ranks` MPI ranks; decompression is one process, a thread per shard
+    (decompression.cpp:174).  Wall time around the whole command, warm page cache."""
+    dst, back = os.path.join(work, "zwz%d" % ranks), os.path.join(work, "back%d" % ranks)
+    cmd = [REF_MAIN] if ranks == 1 else [MPIEXEC, "-n", str(ranks), REF_MAIN]
+    t0 = time.perf_counter()
+    subprocess.run(cmd + ["compress", src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    t1 = time.perf_counter()
+    subprocess.run([REF_MAIN, "decompress", dst, back], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    t2 = time.perf_counter()
+    shutil.rmtree(dst, ignore_errors=True)
+    shutil.rmtree(back, ignore_errors=True)
+    return {"compress_s": round(t1 - t0, 3), "decompress_s": round(t2 - t1, 3),
+            "compress_GBps": round(total_bytes / (t1 - t0) / 1e9, 5), "decompress_GBps": round(total_bytes / (t2 - t1) / 1e9, 5),
+            "roundtrip_GBps": round(total_bytes / (t2 - t0) / 1e9, 5)}
+
+
+def cpu_baseline(workload, host_file, n_files, file_bytes, allow_port):
+    """Reference CPU path on a bounded sample: the first n_files files of the GPU workload (same bytes)."""
     import corpus
     work = tempfile.mkdtemp(prefix="zwz_cpu_")
     try:
+        facts = _cpu_facts(work)
         src = os.path.join(work, "data", "src")
         os.makedirs(src)
         for i in range(n_files):
-            data = corpus.random_bytes(90000 + i, file_bytes) if workload == "random" else corpus.text_like(90000 + i, file_bytes)
             with open(os.path.join(src, "f%05d.bin" % i), "wb") as f:
-                f.write(data)
+                f.write(host_file(i))
         total = n_files * file_bytes
-        dst, back = os.path.join(work, "zwz"), os.path.join(work, "back")
-        ref = os.path.join(ROOT, "oracle", "_ref", "main")
-        kind, cores = None, 1
-        if os.path.exists(ref):
-            try:
-                t0 = time.perf_counter()
-                subprocess.run([ref, "compress", src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-                t1 = time.perf_counter()
-                subprocess.run([ref, "decompress", dst, back], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-                t2 = time.perf_counter()
-                kind, cores = "reference", 2     # producer + consumer threads (compression.cpp:162)
-            except Exception:
-                kind = None
-        if kind is None:
+        sample = "first %d files of the workload (%d x %d B %s, same PRNG and seeds), warm page cache" % (n_files, n_files, file_bytes, workload)
+        if not os.path.exists(REF_MAIN):
+            if not allow_port:
+                return {"value": None, "unit": "GB/s", "cores": 0, "kind": "reference", "sample": sample, "host": facts,
+                        "note": "oracle/_ref/main is absent on this box (it is built from /root/reference by `make -C oracle ref` and is "
+                                "git-ignored); no substitute was timed -- pass --cpu-baseline-port to time the oracle restatement instead"}
             import oracle_binding
             o = oracle_binding.load()
             rec = os.path.join(work, "rec.txt")
             with open(rec, "w") as f:
                 f.write("".join("f%05d.bin\n" % i for i in range(n_files)))
-            os.makedirs(dst, exist_ok=True)
-            os.makedirs(back, exist_ok=True)
+            dst, back = os.path.join(work, "zwz"), os.path.join(work, "back")
+            os.makedirs(dst)
+            os.makedirs(back)
             t0 = time.perf_counter()
             o.compress_shard(src, dst, rec, 0, 1)
             t1 = time.perf_counter()
             o.decompress_shard(os.path.join(dst, "compressed_0.zwz"), back)
             t2 = time.perf_counter()
-            kind, cores = "port", 1
-        return {"value": round(total / (t2 - t0) / 1e9, 5), "unit": "GB/s", "cores": cores, "kind": kind,
-                "sample": "%d x %d B %s files, 1 rank: compress %.2f s + decompress %.2f s (warm page cache)"
-                          % (n_files, file_bytes, workload, t1 - t0, t2 - t1),
-                "compress_GBps": round(total / (t1 - t0) / 1e9, 5), "decompress_GBps": round(total / (t2 - t1) / 1e9, 5)}
+            return {"value": round(total / (t2 - t0) / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port", "sample": sample, "host": facts,
+                    "compress_GBps": round(total / (t1 - t0) / 1e9, 5), "decompress_GBps": round(total / (t2 - t1) / 1e9, 5)}
+        ranks = {}
+        ks = [1, 2, 4, 8] if os.path.exists(MPIEXEC) else [1]
+        for k in ks:
+            ranks[str(k)] = _time_reference(src, work, total, k)
+        out = {"value": ranks["1"]["roundtrip_GBps"], "unit": "GB/s", "cores": 2, "kind": "reference", "sample": sample, "host": facts,
+               "compress_GBps": ranks["1"]["compress_GBps"], "decompress_GBps": ranks["1"]["decompress_GBps"],
+               "cores_note": "value = 1 MPI rank = producer + consumer thread (compression.cpp:162); ranks[K] uses 2K threads to compress and K threads (one per shard) to decompress",
+               "ranks": ranks}
+        if not os.path.exists(MPIEXEC):
+            out["ranks_note"] = "no mpiexec on this box: the reference runs as an MPI singleton only"
+        if workload == "random":           # BASELINE configs[0] as such: 100 x 1 MiB random files, 1 rank
+            shutil.rmtree(src)
+            os.makedirs(src)
+            for i in range(100):
+                with open(os.path.join(src, "m%03d.bin" % i), "wb") as f:
+                    f.write(corpus.random_bytes(500_000 + i, 1 << 20))
+            out["config1_100x1MiB"] = _time_reference(src, work, 100 << 20, 1)
+        return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
+# ------------------------------------------------------------------------------------------------ verification
+def verify_bytes(torch, d_in, d_len, d_olen, d_back, d_blen, d_stat):
+    """Every chunk, on the device: the decoded bytes are the input's bytes.  A chunk either comes back whole, or it is one
+    the reference truncates (payload at the 65535-byte cap, decoder ran out of input) and comes back as a PREFIX."""
+    n = d_len.numel()
+    ok_len = ((d_blen == d_len) | ((d_olen == CHUNK) & (d_stat == 1) & (d_blen < d_len)))
+    a, b = d_in.view(n, STRIDE), d_back.view(n, STRIDE)
+    col = torch.arange(STRIDE, device=d_in.device, dtype=torch.int32).view(1, -1)
+    bad = 0
+    for c0 in range(0, n, 2048):
+        c1 = min(n, c0 + 2048)
+        live = col < d_blen[c0:c1].view(-1, 1)
+        bad += int(((a[c0:c1] != b[c0:c1]) & live).any(dim=1).sum().item())
+    return {"chunks": n, "length_rule_ok": bool(ok_len.all().item()), "chunks_with_wrong_bytes": bad,
+            "truncated_chunks": int((d_blen < d_len).sum().item())}
+
+
+def verify_oracle_sample(torch, k, d_in, d_len, d_out, d_olen, d_back, d_blen):
+    """k chunks spread over the batch: payload == oracle's payload, decoded bytes == oracle's decode of it."""
+    import oracle_binding
+    o = oracle_binding.load()
+    n = d_len.numel()
+    idx = sorted(set(int(i * (n - 1) / max(1, k - 1)) for i in range(min(k, n))))
+    t = torch.tensor(idx, dtype=torch.int64, device=d_in.device)
+    h_in = d_in.view(n, STRIDE)[t].cpu().numpy()
+    h_out = d_out.view(n, STRIDE)[t].cpu().numpy()
+    h_back = d_back.view(n, STRIDE)[t].cpu().numpy()
+    lens, olens, blens = d_len[t].cpu().tolist(), d_olen[t].cpu().tolist(), d_blen[t].cpu().tolist()
+    bad_payload = bad_decode = 0
+    for j in range(len(idx)):
+        chunk = h_in[j, :lens[j]].tobytes()
+        want = o.payload(chunk)
+        if h_out[j, :olens[j]].tobytes() != want:
+            bad_payload += 1
+        if h_back[j, :blens[j]].tobytes() != o.inflate(want, 70000)[0]:
+            bad_decode += 1
+    return {"sampled": len(idx), "payload_mismatches": bad_payload, "decode_mismatches": bad_decode}
+
+
+# ------------------------------------------------------------------------------------------------ one workload
+def run_workload(args, torch, dist, codec, dev, world, rank, name):
+    import workloads
+    cpu_dev = torch.device("cpu")
+    decompress_only = args.decompress_only
+    scaling = "weak"
+    if name in ("random", "text"):
+        n_files = args.files or 10000
+        d_in, d_off, d_len, n, raw_bytes, host_file = workloads.build_equal_files(torch, dev, name, n_files, args.file_bytes, rank)
+        desc = "%d x %d B %s files per GPU -> %d chunks of <=65535 B (BASELINE configs[%d])" % (
+            n_files, args.file_bytes, "incompressible random" if name == "random" else "text-like", n, 1 if name == "random" else 2)
+        cpu_files, cpu_file_bytes = min(args.cpu_sample_files, n_files), args.file_bytes
+    elif name == "small_files":
+        n_files = args.files or 370000
+        d_in, d_off, d_len, n, raw_bytes, host_file = workloads.build_small_files(torch, dev, n_files, rank)
+        desc = "%d image-like files per GPU, log-normal sizes, %.2f GB -> %d chunks (BASELINE configs[3], reference README.md:12-13)" % (n_files, raw_bytes / 1e9, n)
+        cpu_files = 0
+    else:   # one_file: ONE text-like file; its records are split over the ranks in contiguous ranges (strong scaling)
+        total = args.one_file_bytes
+        n_all = total // CHUNK + 1
+        j0, j1 = n_all * rank // world, n_all * (rank + 1) // world
+        n = j1 - j0
+        block, _, _, _, _, _ = workloads.build_equal_files(torch, cpu_dev, "text", 64, 1 << 20, 0, distinct_text=64)
+        flat_src = block.view(64 * 17, STRIDE)[:, :CHUNK]                     # text in 65 535-byte rows (last row of a file is short: skip those)
+        rows = flat_src[[i for i in range(64 * 17) if i % 17 != 16]].contiguous().to(dev)      # 1024 full rows of text
+        d_in = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
+        view = d_in.view(n, STRIDE)
+        for c0 in range(0, n, 1024):
+            c1 = min(n, c0 + 1024)
+            view[c0:c1, :CHUNK] = rows[:c1 - c0]
+        lens = torch.full((n,), CHUNK, dtype=torch.int32, device=dev)
+        if j1 == n_all:
+            lens[-1] = total % CHUNK
+        d_len, d_off = lens, torch.arange(n, dtype=torch.int64, device=dev) * STRIDE
+        raw_bytes = int(d_len.sum().item())
+        host_file, cpu_files = None, 0
+        scaling = "strong"
+        desc = "ONE %.1f GB text-like file = %d records in one shard, split into %d contiguous record ranges (BASELINE configs[4] scaled: 64 GiB there)" % (total / 1e9, n_all, world)
+    d_out = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)
+    d_olen = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_back = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)
+    d_blen = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_stat = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def deflate():
+        codec.deflate_dev(d_in, d_off, d_len, d_out, d_olen)
+
+    def inflate():
+        codec.inflate_dev(d_out, d_off, d_olen, d_back, d_blen, d_stat)
+
+    def step():
+        if not decompress_only:
+            deflate()
+        inflate()
+
+    def fence():
+        codec.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    if decompress_only:
+        deflate()                    # the shard is made once, outside every timed region
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cpu_dev if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # direction split + per-kernel times (untimed extra passes, HIP events on the codec's stream)
+    fence()
+    c0 = time.perf_counter(); deflate(); codec.sync(); c1 = time.perf_counter()
+    inflate(); codec.sync(); c2 = time.perf_counter()
+    codec.set_profiling(True)
+    codec.stage_ms(reset=True)
+    prof_passes = 2
+    for _ in range(prof_passes):
+        deflate()
+        inflate()
+    codec.sync()
+    stage = codec.stage_ms(reset=True)
+    codec.set_profiling(False)
+
+    payload_bytes = int(d_olen.sum().item())
+    back_bytes = int(d_blen.sum().item())
+    verified = verify_bytes(torch, d_in, d_len, d_olen, d_back, d_blen, d_stat)
+    verified["oracle"] = verify_oracle_sample(torch, args.oracle_sample, d_in, d_len, d_out, d_olen, d_back, d_blen)
+    verified["ok"] = bool(verified["length_rule_ok"] and verified["chunks_with_wrong_bytes"] == 0 and
+                          verified["oracle"]["payload_mismatches"] == 0 and verified["oracle"]["decode_mismatches"] == 0)
+    raw_all = raw_bytes
+    if world > 1:
+        tot = torch.tensor([float(raw_bytes)], dtype=torch.float64, device=cpu_dev if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        raw_all = float(tot.item())
+        flag = torch.tensor([0.0 if verified["ok"] else 1.0], dtype=torch.float64, device=cpu_dev if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        verified["ranks_failed"] = int(flag.item())
+        verified["ok"] = verified["ok"] and flag.item() == 0
+
+    res = None
+    if rank == 0:
+        launches_per_pass = (n + args.max_batch - 1) // args.max_batch
+        timed = {k: v for k, v in stage.items() if not (decompress_only and k != "inflate")}
+        dom = max(timed, key=lambda k: timed[k])
+        dom_launches = launches_per_pass * prof_passes if dom != "inflate" else prof_passes
+        dom_ms = stage[dom] / dom_launches
+        algo_bytes = (raw_bytes + payload_bytes) if dom != "inflate" else (payload_bytes + back_bytes)
+        algo_per_launch = algo_bytes / (dom_launches / prof_passes)
+        achieved = algo_per_launch / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+        if os.path.exists(tpath) and name in ("random", "text") and (args.files or 10000) == 10000 and args.file_bytes == 262144:
+            # PMC passes of this same workload, collected separately (tools/prof_gpu.sh); null if not measured
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        comp_s, dec_s = c1 - c0, c2 - c1
+        res = {
+            "value": round(raw_all * args.steps / elapsed / 1e9, 3), "unit": "GB/s",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "scaling": scaling,
+            "config": {"workload": desc, "chunk_bytes": CHUNK, "max_batch_chunks": args.max_batch,
+                       "parallelism": ("record-range-per-gpu x%d" if name == "one_file" else "shard-per-gpu x%d") % world,
+                       "timed": "inflate only" if decompress_only else "deflate + inflate"},
+            "compress_GBps": round(raw_bytes / comp_s / 1e9, 3), "decompress_GBps": round(raw_bytes / dec_s / 1e9, 3),
+            "payload_ratio": round(payload_bytes / raw_bytes, 4), "verified": verified,
+            "stage_ms_per_pass": {k: round(v / prof_passes, 3) for k, v in stage.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(algo_per_launch), "launch_ms": round(dom_ms, 4),
+                         # whole directions: algorithmic bytes (raw + payload) / wall time of the direction
+                         "compress_frac_of_8TBps": round((raw_bytes + payload_bytes) / comp_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "compress_frac_of_6.29TBps": round((raw_bytes + payload_bytes) / comp_s / 1e9 / HBM_ACHIEVABLE_GBS, 5),
+                         "decompress_frac_of_8TBps": round((payload_bytes + back_bytes) / dec_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "decompress_frac_of_6.29TBps": round((payload_bytes + back_bytes) / dec_s / 1e9 / HBM_ACHIEVABLE_GBS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline and cpu_files:
+            res["cpu_baseline"] = cpu_baseline(name, host_file, cpu_files, cpu_file_bytes, args.cpu_baseline_port)
+    del d_in, d_out, d_back
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))          # children get WORLD_SIZE; this process never touches the GPU
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -163,90 +408,26 @@ def main():
         dist.barrier()
     codec = zwz.Codec(local, args.max_batch)
 
-    d_in, d_off, d_len, n, raw_bytes = build_batch(torch, dev, args.workload, args.files, args.file_bytes, 1234 + rank)
-    d_out = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)
-    d_olen = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_back = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)
-    d_blen = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_stat = torch.zeros(n, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def step():
-        codec.deflate_dev(d_in, d_off, d_len, d_out, d_olen)
-        codec.inflate_dev(d_out, d_off, d_olen, d_back, d_blen, d_stat)
-
-    def fence():
-        codec.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_on_one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # direction split + per-kernel times (untimed extra passes, HIP events on the codec's stream)
-    fence()
-    c0 = time.perf_counter(); codec.deflate_dev(d_in, d_off, d_len, d_out, d_olen); codec.sync(); c1 = time.perf_counter()
-    codec.inflate_dev(d_out, d_off, d_olen, d_back, d_blen, d_stat); codec.sync(); c2 = time.perf_counter()
-    codec.set_profiling(True)
-    codec.stage_ms(reset=True)
-    prof_passes = 2
-    for _ in range(prof_passes):
-        step()
-    codec.sync()
-    stage = codec.stage_ms(reset=True)
-    codec.set_profiling(False)
-
-    payload_bytes = int(d_olen.sum().item())
-    back_bytes = int(d_blen.sum().item())
-    # parity property on the full batch: every chunk either round-trips or is a reference-truncated one
-    ok = bool(((d_blen == d_len) | ((d_olen == CHUNK) & (d_stat == 1))).all().item())
-
+    names = ["random", "text"] if args.workload == "both" else [args.workload]
+    results = [run_workload(args, torch, dist, codec, dev, world, rank, nm) for nm in names]
     if rank == 0:
-        launches_per_pass = (n + args.max_batch - 1) // args.max_batch
-        dom = max(stage, key=lambda k: stage[k])
-        dom_launches = launches_per_pass * prof_passes if dom != "inflate" else prof_passes
-        dom_ms = stage[dom] / dom_launches
-        algo_bytes = (raw_bytes + payload_bytes) if dom != "inflate" else (payload_bytes + back_bytes)
-        algo_per_launch = algo_bytes / (dom_launches / prof_passes)
-        achieved = algo_per_launch / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath) and args.files == 10000 and args.file_bytes == 262144:
-            # PMC pass of this same command, collected separately (tools_prof.sh); null if not measured
-            traffic = json.load(open(tpath)).get(dom.replace("lz_", "lz_"), {}).get("hbm_bytes_per_launch")
-        line = {
-            "metric": "compress+decompress GB/s (raw bytes / (deflate + inflate time)), .zwz bit-exact",
-            "value": round(world * raw_bytes * args.steps / elapsed / 1e9, 3), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d x %d B %s files per GPU -> %d chunks of <=65535 B (BASELINE configs[%d])"
-                                   % (args.files, args.file_bytes, args.workload, n, 1 if args.workload == "random" else 2),
-                       "chunk_bytes": CHUNK, "max_batch_chunks": args.max_batch, "parallelism": "shard-per-gpu x%d" % world},
-            "compress_GBps": round(raw_bytes / (c1 - c0) / 1e9, 3), "decompress_GBps": round(raw_bytes / (c2 - c1) / 1e9, 3),
-            "payload_ratio": round(payload_bytes / raw_bytes, 4), "roundtrip_property_ok": ok,
-            "stage_ms_per_pass": {k: round(v / prof_passes, 3) for k, v in stage.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(algo_per_launch), "launch_ms": round(dom_ms, 4)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.file_bytes, args.cpu_sample_files)
+        head = results[0]
+        line = {"metric": "compress+decompress GB/s (raw bytes / (deflate + inflate time)), .zwz bit-exact",
+                "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic (own splitmix64 PRNG, seeds in tests/workloads.py)"}
+        for k, v in head.items():
+            line.setdefault(k, v)
+        for nm, r in zip(names[1:], results[1:]):
+            line[nm] = r
         print(json.dumps(line), flush=True)
+    ok = all(r is None or r["verified"]["ok"] for r in results)
     codec.close()
     if world > 1:
         dist.destroy_process_group()
+    if not ok:
+        sys.stderr.write("bench.py: verification FAILED (see \"verified\" in the JSON line)\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,7 @@ extern "C" {
 #define ZWZ_CHUNK_SIZE 65535u      /* process.hpp:12 CHUNK_SIZE */
 #define ZWZ_DEV_STRIDE 65536u      /* chunk slot stride in device buffers (16-byte aligned slots) */
 #define ZWZ_MD5_HEX_LEN 32u        /* process.hpp:14 MD5_DATA_SIZE */
+#define ZWZ_LOSSLESS_CHUNK_SIZE 65504u /* opt-in: largest chunk whose stream always fits 65535 bytes */
 
 typedef enum zwz_status {
     ZWZ_OK = 0,
@@ -118,8 +119,31 @@ int zwz_md5_of_file(const char *path, char hex_out[33]);
 int zwz_compress_dir(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, const char *file_record, int rank,
                      int nranks);
 /* Every <src>/ *.zwz -> files under <dst>; md5_mismatches (optional) counts files whose MD5
- * differs from the stored one (the reference only prints them, decompression.cpp:140-146). */
+ * differs from the stored one (the reference only prints them, decompression.cpp:140-146).
+ * A shard that ends inside a record is decoded up to the damage (as the reference's reader would) and the
+ * call returns ZWZ_E_FORMAT. */
 int zwz_decompress_dir(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, int *md5_mismatches);
+
+/* The same job shared by nranks processes, one GPU each (the reference parallelises over shards only,
+ * decompression.cpp:165-178, and decodes inside a shard serially, :65-154).  Shards are taken in name order: with at
+ * least nranks of them, shard j belongs to rank j % nranks and no rank talks to another.  With fewer (BASELINE config 5:
+ * one shard holding one huge file) every shard is split: rank r inflates the r-th contiguous range of its records, and
+ * the ranks all-gather how many bytes each decoded (a chunk's place in its file is the sum of the decoded lengths in
+ * front of it).  `exchange` is that all-gather: every rank calls it with `count` values in `mine` and receives
+ * nranks * count values, rank-major, in `all`; it returns 0 on success.  It doubles as the barrier before MD5
+ * verification, is called the same number of times on every rank, and may be NULL when nranks == 1 or there is a shard
+ * per rank.  The launcher supplies it: torch.distributed / RCCL (cli.py), marker files (csrc/main.cpp).  <dst> must be
+ * one file system for all ranks.  md5_mismatches counts the files THIS rank verified. */
+typedef int (*zwz_allgather_u64_fn)(void *user, const uint64_t *mine, uint64_t *all, uint32_t count);
+int zwz_decompress_dir_ranked(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, int rank, int nranks,
+                              zwz_allgather_u64_fn exchange, void *user, int *md5_mismatches);
+
+/* Opt-in, never the default, NOT bit-exact with the reference's shards: raw bytes per Chunk for
+ * zwz_compress_dir, 1..65535; 0 restores the reference's 65535 (process.hpp:12).  ZWZ_LOSSLESS_CHUNK_SIZE (65504) is the
+ * largest size whose level-6 stream always fits the reference's 65535-byte payload buffer (compression.cpp:127-132), so
+ * nothing is truncated and every file round-trips with a matching MD5; the container is unchanged and the reference's
+ * decoder reads such shards.  The environment variables ZWZ_LOSSLESS=1 / ZWZ_CHUNK_SIZE=<n> do the same for the CLI. */
+int zwz_ctx_set_chunk_size(zwz_ctx *ctx, uint32_t bytes);
 
 #ifdef __cplusplus
 }

@@ -156,10 +156,24 @@ int zo_decompress_shard(const char *shard_path, const char *out_dir) {
         memcpy(&seq, sh + p, 4); p += 4;
         uint8_t last = sh[p++];
         int32_t plen = total - (4 + path_len + 4 + 1);
-        if (plen < 0 || p + (size_t)plen > sz) { free(rel); break; }
-        const uint8_t *payload = sh + p; p += (size_t)plen;
+        if (plen < 0 || plen > 65535) { free(rel); break; }
+        /* A shard that ends inside a record (decompression.cpp:82-92): the reference reads the payload into a zero-filled
+         * vector of the declared size and the MD5 into a zero-filled string, processes the record, then stops at eof. */
+        int damaged = 0;
+        uint8_t *padded = NULL;
+        const uint8_t *payload = sh + p;
+        if (p + (size_t)plen > sz) {
+            damaged = 1;
+            padded = (uint8_t *)calloc((size_t)plen + 1, 1);
+            memcpy(padded, sh + p, sz - p);
+            payload = padded; p = sz;
+        } else p += (size_t)plen;
         char md5[33] = {0};
-        if (last) { if (p + 32 > sz) { free(rel); break; } memcpy(md5, sh + p, 32); p += 32; }
+        if (last) {
+            size_t have = sz - p < 32 ? sz - p : 32;
+            memcpy(md5, sh + p, have); p += have;
+            if (have < 32) damaged = 1;
+        }
 
         ofile_t *of = open_files;
         while (of && strcmp(of->rel, rel)) of = of->next;
@@ -168,7 +182,7 @@ int zo_decompress_shard(const char *shard_path, const char *out_dir) {
         if (!of) {
             mkdirs_for(file_path);
             FILE *f = fopen(file_path, "wb");
-            if (!f) { free(rel); continue; }
+            if (!f) { free(rel); free(padded); if (damaged) break; continue; }
             of = (ofile_t *)calloc(1, sizeof *of);
             of->rel = strdup(rel); of->f = f; of->next = open_files; open_files = of;
         }
@@ -204,6 +218,8 @@ int zo_decompress_shard(const char *shard_path, const char *out_dir) {
             pd->next = of->pend; of->pend = pd;
         }
         free(rel);
+        free(padded);
+        if (damaged) break;
     }
     while (open_files) {
         ofile_t *of = open_files; open_files = of->next;

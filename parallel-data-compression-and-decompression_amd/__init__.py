@@ -22,13 +22,21 @@ DEV_STRIDE = 65536
 NUM_STAGES = 7
 STAGE_NAMES = ("lz_links", "lz_match", "lz_parse", "blockify", "plan", "encode", "inflate")
 
+LOSSLESS_CHUNK_SIZE = 65504  # opt-in, never default (include/zwz.h: zwz_ctx_set_chunk_size)
+# zwz_allgather_u64_fn: int (*)(void *user, const uint64_t *mine, uint64_t *all, uint32_t count)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                ctypes.c_uint32)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzwz_hip.so")
 _lib = None
 
 
 class ZwzError(RuntimeError):
-    pass
+    """A non-zero status from the C ABI.  .status is the zwz_status code; a failed do_decompression also carries
+    .md5_mismatches (a damaged shard is decoded up to the damage before ZWZ_E_FORMAT is returned)."""
+    status = None
+    md5_mismatches = None
 
 
 def lib():
@@ -63,14 +71,23 @@ def lib():
         L.zwz_md5_files_dev.argtypes = [vp, vp, vp, vp, vp, u32, vp]
         L.zwz_compress_dir.argtypes = [vp, c.c_char_p, c.c_char_p, c.c_char_p, c.c_int, c.c_int]
         L.zwz_decompress_dir.argtypes = [vp, c.c_char_p, c.c_char_p, c.POINTER(c.c_int)]
+        L.zwz_decompress_dir_ranked.argtypes = [vp, c.c_char_p, c.c_char_p, c.c_int, c.c_int, ALLGATHER_FN, vp, c.POINTER(c.c_int)]
+        L.zwz_ctx_set_chunk_size.argtypes = [vp, u32]
         _lib = L
     return _lib
 
 
-def _check(rc, what):
+E_FORMAT = -6
+
+
+def _check(rc, what, **extra):
     if rc != 0:
         L = lib()
-        raise ZwzError("%s: %s (%s)" % (what, L.zwz_strerror(rc).decode(), L.zwz_last_error().decode()))
+        err = ZwzError("%s: %s (%s)" % (what, L.zwz_strerror(rc).decode(), L.zwz_last_error().decode()))
+        err.status = rc
+        for k, v in extra.items():
+            setattr(err, k, v)
+        raise err
 
 
 def device_count():
@@ -174,11 +191,34 @@ class Codec:
         _check(lib().zwz_compress_dir(self._h, os.fsencode(input_dir), os.fsencode(output_dir), os.fsencode(file_record),
                                       world_rank, world_size), "zwz_compress_dir")
 
-    def do_decompression(self, input_dir, output_dir):
+    def do_decompression(self, input_dir, output_dir, world_rank=0, world_size=1, allgather=None):
+        """do_decompression(), decompression.cpp:165-178, shared by world_size ranks (one GPU each): whole shards round-robin,
+        or record ranges of a shard when there are fewer shards than ranks.  `allgather(values) -> list of every rank's
+        values, rank-major` is the launcher's exchange (cli.py passes torch.distributed's); returns the number of files
+        this rank found with a wrong MD5."""
         bad = ctypes.c_int(0)
-        _check(lib().zwz_decompress_dir(self._h, os.fsencode(input_dir), os.fsencode(output_dir), ctypes.byref(bad)),
-               "zwz_decompress_dir")
+
+        def _cb(_user, mine, out, count):
+            try:
+                flat = allgather([int(mine[i]) for i in range(count)])
+                for i, v in enumerate(flat):
+                    out[i] = int(v)
+                return 0
+            except Exception:          # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        cb = ALLGATHER_FN(_cb) if allgather is not None else ctypes.cast(None, ALLGATHER_FN)
+        rc = lib().zwz_decompress_dir_ranked(self._h, os.fsencode(input_dir), os.fsencode(output_dir), world_rank, world_size,
+                                             cb, None, ctypes.byref(bad))
+        _check(rc, "zwz_decompress_dir", md5_mismatches=bad.value)
         return bad.value
+
+    def set_chunk_size(self, nbytes):
+        """Raw bytes per Chunk for do_compression (0 = the reference's 65535).  Opt-in, not bit-exact with the reference's
+        shards; LOSSLESS_CHUNK_SIZE never truncates."""
+        _check(lib().zwz_ctx_set_chunk_size(self._h, nbytes), "zwz_ctx_set_chunk_size")
 
 
 def sort_files_by_size(path):
@@ -211,5 +251,5 @@ def do_compression(input_dir, output_dir, file_record, world_rank, world_size=1)
     _codec().do_compression(input_dir, output_dir, file_record, world_rank, world_size)
 
 
-def do_decompression(input_dir, output_dir):
-    return _codec().do_decompression(input_dir, output_dir)
+def do_decompression(input_dir, output_dir, world_rank=0, world_size=1, allgather=None):
+    return _codec().do_decompression(input_dir, output_dir, world_rank, world_size, allgather)

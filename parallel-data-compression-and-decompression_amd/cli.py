@@ -14,7 +14,8 @@ over xGMI when GPUs are present, "gloo" otherwise):
     (addition, --gather) per-shard .zwz blobs collected on rank 0 for hosts without a shared output
         directory; the reference has no gather (every rank writes compressed_<rank>.zwz itself)
 
-Decompression is a single-rank job in the reference (main.cpp:61-68) and here.
+    (addition) decompression is a single-rank job in the reference (main.cpp:61-68); here shard j goes to rank j mod N,
+        and fewer shards than ranks are split by record ranges with an all_gather of decoded byte counts
 """
 import argparse
 import os
@@ -46,7 +47,9 @@ def broadcast_bytes(data, src=0):
 
 
 def gather_blobs(blob, dst=0):
-    """Every rank's bytes on rank dst (list indexed by rank), None elsewhere."""
+    """Every rank's bytes on rank dst (list indexed by rank), None elsewhere: an all-gather of the sizes (8 bytes a
+    rank), then each rank sends its shard to dst and nowhere else (RCCL has no gatherv; an all-gather of padded shards
+    would leave every shard on every GPU)."""
     import torch
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -55,15 +58,38 @@ def gather_blobs(blob, dst=0):
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([len(blob)], dtype=torch.int64, device=dev))
-    cap = max(int(s.item()) for s in sizes)
-    mine = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
-    if blob:
-        mine[:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)          # RCCL has no gatherv; shards are padded to the largest
+    sizes = [int(s.item()) for s in sizes]
     if rank != dst:
+        if sizes[rank]:
+            mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            dist.send(mine, dst)
         return None
-    return [bytes(p[:int(s.item())].cpu().numpy().tobytes()) for p, s in zip(parts, sizes)]
+    out = []
+    for r in range(world):
+        if r == dst:
+            out.append(blob)
+        elif sizes[r] == 0:
+            out.append(b"")
+        else:
+            buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+            dist.recv(buf, r)
+            out.append(bytes(buf.cpu().numpy().tobytes()))
+    return out
+
+
+def allgather_u64(values):
+    """The exchange zwz_decompress_dir_ranked asks for (include/zwz.h: zwz_allgather_u64_fn): every rank's list of unsigned
+    64-bit values on every rank, rank-major.  Doubles as a barrier."""
+    import torch
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(values)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    signed = [v - (1 << 64) if v >= (1 << 63) else v for v in values]           # torch has no uint64 collectives
+    mine = torch.tensor(signed, dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [int(x) & ((1 << 64) - 1) for p in parts for x in p.cpu().tolist()]
 
 
 def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=None, sort_fn=None, count_fn=None,
@@ -130,10 +156,10 @@ def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=
                                 g.write(b)
         finally:
             os.unlink(local_record)
-    elif rank == 0:                                                  # main.cpp:61-68
-        if world > 1:
-            print("Decompression is not supported in MPI parallel mode.\nOnly use one process to decompress.", file=out)
-        decompress_fn(source_path, output_path)
+    else:
+        # The reference decodes on rank 0 only (main.cpp:61-68); here every rank takes its share: whole shards round-robin,
+        # or record ranges of a shard when there are fewer shards than ranks.
+        decompress_fn(source_path, output_path, rank, world, allgather_u64 if world > 1 else None)
 
     if world > 1:
         dist.barrier()
@@ -148,7 +174,7 @@ def main(argv=None):
     ap.add_argument("operation")
     ap.add_argument("source")
     ap.add_argument("output")
-    ap.add_argument("--gather", action="store_true", help="collect every rank's shard on rank 0 (RCCL all_gather)")
+    ap.add_argument("--gather", action="store_true", help="collect every rank's shard on rank 0 (RCCL send/recv)")
     args = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:

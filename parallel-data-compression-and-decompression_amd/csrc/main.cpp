@@ -2,37 +2,207 @@
 // over the GPU pipeline.  Same argv, same output names (<dst>/compressed_<rank>.zwz, the side file
 // <parent(src)>/sorted_files_by_size.txt), same final banner.  One process drives one GPU; rank and
 // world size come from the launcher's environment (ZWZ_RANK/ZWZ_NRANKS, else RANK/WORLD_SIZE, else
-// OMPI/PMI variables, else 0/1) where the reference asked MPI.  Ranks meet through marker files in
-// <dst> (the reference likewise assumes a shared file system for the list, compression.cpp:25);
-// the torch.distributed launcher (python -m ... cli) uses RCCL for the same two steps.
+// OMPI/PMI variables, else 0/1) where the reference asked MPI.
+//
+// What the reference does with MPI (two broadcasts of the record PATH, main.cpp:27,35; three barriers, :41,131,144)
+// this binary does through small marker files in <dst> -- the reference likewise assumes one file system for the list
+// and the shards (compression.cpp:25).  The torch.distributed launcher (python -m ... cli) uses RCCL for the same steps.
+// The markers cannot be confused with those of an earlier run that crashed and left its own behind:
+//   * every name carries a run id (ZWZ_RUN_ID, else the launcher's pid + start time: ranks of one launch share a parent);
+//   * every rank announces itself with a nonce (pid + start time); rank 0 publishes the list path together with its own
+//     nonce and every nonce it has seen, atomically (write + rename), and keeps adding late arrivals; a rank only accepts
+//     a publication that names its nonce, i.e. one written by a rank 0 that has seen THIS process;
+//   * completion markers carry rank 0's nonce and the rank's return code; rank 0 fails if a rank failed or never arrived.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
+#include <vector>
 
+#include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/zwz.h"
 
-static int env_int(const char* const* names, int dflt) {
+namespace {
+
+int env_int(const char* const* names, int dflt) {
     for (; *names; names++) if (const char* v = getenv(*names)) return atoi(v);
     return dflt;
 }
 
-static bool wait_for(const std::string& path, double seconds) {
-    auto t0 = std::chrono::steady_clock::now();
-    struct stat sb;
-    while (stat(path.c_str(), &sb) != 0) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
-    }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+std::string start_time_of(long pid) {          // field 22 of /proc/<pid>/stat: start time in clock ticks since boot
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+    FILE* f = fopen(path, "r");
+    if (!f) return "0";
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char* p = strrchr(buf, ')');          // the command name may contain spaces
+    if (!p) return "0";
+    int field = 2;
+    for (p++; *p; p++) if (*p == ' ' && ++field == 22) { p++; break; }
+    std::string s;
+    for (; *p && *p != ' '; p++) s += *p;
+    return s.empty() ? "0" : s;
+}
+
+bool write_atomic(const std::string& path, const std::string& content) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "w");
+    if (!f) return false;
+    const bool ok = fwrite(content.data(), 1, content.size(), f) == content.size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); return false; }
     return true;
 }
 
-static void touch(const std::string& path) { if (FILE* f = fopen(path.c_str(), "w")) fclose(f); }
+bool read_all(const std::string& path, std::string& out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    out.clear();
+    char buf[4096];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, k);
+    fclose(f);
+    return true;
+}
+
+std::vector<std::string> names_with_prefix(const std::string& dir, const std::string& prefix) {
+    std::vector<std::string> out;
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* e = readdir(d)) if (!strncmp(e->d_name, prefix.c_str(), prefix.size()) && !strstr(e->d_name, ".tmp")) out.push_back(e->d_name);
+        closedir(d);
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+std::vector<std::string> lines_of(const std::string& s) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    while (p <= s.size()) {
+        const size_t e = s.find('\n', p);
+        if (e == std::string::npos) { if (p < s.size()) out.push_back(s.substr(p)); break; }
+        out.push_back(s.substr(p, e - p));
+        p = e + 1;
+    }
+    return out;
+}
+
+// The ranks of one launch, meeting through files named <dir>/<stem>_*.
+struct Rendezvous {
+    std::string dir, stem;          // stem = ".zwz_<op>_<run id>"
+    int rank = 0, world = 1;
+    std::string nonce, nonce0;      // mine; rank 0's (known once published / accepted)
+    std::string payload;            // what rank 0 publishes beside the nonces (the record path)
+    std::vector<std::string> seen;  // rank 0: nonces published so far
+    double timeout_s = 600;
+    uint32_t round = 0;
+
+    std::string path(const std::string& tail) const { return dir + "/" + stem + "_" + tail; }
+
+    void hello() { if (rank != 0) write_atomic(path("here_" + std::to_string(rank) + "_" + nonce), nonce + "\n"); }
+
+    // rank 0: (re)publish payload + every announced nonce; true once every rank has announced itself at least once
+    bool publish() {
+        std::vector<std::string> nonces;
+        std::vector<bool> have((size_t)world, false);
+        have[0] = true;
+        for (const std::string& n : names_with_prefix(dir, stem + "_here_")) {
+            const std::string rest = n.substr(stem.size() + 6);               // "<rank>_<nonce>"
+            const size_t us = rest.find('_');
+            if (us == std::string::npos) continue;
+            const int r = atoi(rest.substr(0, us).c_str());
+            if (r > 0 && r < world) { have[(size_t)r] = true; nonces.push_back(rest.substr(us + 1)); }
+        }
+        if (nonces != seen) {
+            std::string content = nonce + "\n" + payload + "\n";
+            for (const std::string& n : nonces) content += n + "\n";
+            if (write_atomic(path("list_" + nonce), content)) seen = nonces;
+        }
+        return std::all_of(have.begin(), have.end(), [](bool b) { return b; });
+    }
+
+    // rank 0: publish and wait until every rank of the launch has announced itself (MPI_Barrier, main.cpp:41)
+    bool publish_to_all() {
+        const double t0 = now_s();
+        while (!publish()) {
+            if (now_s() - t0 > timeout_s) return false;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        return true;
+    }
+
+    // rank > 0: wait for a publication that names this process
+    bool accept() {
+        const double t0 = now_s();
+        for (;;) {
+            for (const std::string& n : names_with_prefix(dir, stem + "_list_")) {
+                std::string content;
+                if (!read_all(dir + "/" + n, content)) continue;
+                const std::vector<std::string> ls = lines_of(content);
+                if (ls.size() >= 2 && std::find(ls.begin() + 2, ls.end(), nonce) != ls.end()) { nonce0 = ls[0]; payload = ls[1]; return true; }
+            }
+            if (now_s() - t0 > timeout_s) return false;
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    }
+
+    // all-gather of `count` 64-bit values per rank (zwz_allgather_u64_fn); also a barrier
+    int allgather(const uint64_t* mine, uint64_t* all, uint32_t count) {
+        const std::string tag = "x" + std::to_string(round++) + "_";
+        std::string content;
+        for (uint32_t i = 0; i < count; i++) content += std::to_string((unsigned long long)mine[i]) + "\n";
+        if (!write_atomic(path(tag + std::to_string(rank) + "_" + nonce0), content)) return -1;
+        const double t0 = now_s();
+        for (int r = 0; r < world; r++) {
+            std::string got;
+            while (!read_all(path(tag + std::to_string(r) + "_" + nonce0), got)) {
+                if (rank == 0) publish();                                       // late arrivals still need the publication
+                if (now_s() - t0 > timeout_s) return -1;
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+            const std::vector<std::string> ls = lines_of(got);
+            if (ls.size() < count) return -1;
+            for (uint32_t i = 0; i < count; i++) all[(size_t)r * count + i] = strtoull(ls[i].c_str(), nullptr, 10);
+        }
+        return 0;
+    }
+
+    // MPI_Barrier + status (main.cpp:144): every rank reports its return code; rank 0 collects them and cleans up
+    int finish(int rc) {
+        if (world <= 1) return rc;
+        if (!nonce0.empty()) write_atomic(path("done_" + std::to_string(rank) + "_" + nonce0), std::to_string(rc) + "\n");
+        if (rank != 0) return rc;
+        const double t0 = now_s();
+        int worst = rc;
+        for (int r = 1; r < world; r++) {
+            std::string got;
+            while (!read_all(path("done_" + std::to_string(r) + "_" + nonce0), got)) {
+                publish();
+                if (now_s() - t0 > (getenv("ZWZ_RENDEZVOUS_TIMEOUT") ? timeout_s : 3600.0)) { fprintf(stderr, "rank 0: rank %d never reported completion\n", r); return worst ? worst : 3; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            const int rr = atoi(got.c_str());
+            if (rr != 0) { fprintf(stderr, "rank 0: rank %d failed with status %d\n", r, rr); if (!worst) worst = rr; }
+        }
+        for (const std::string& n : names_with_prefix(dir, stem + "_")) unlink((dir + "/" + n).c_str());
+        return worst;
+    }
+};
+
+int exchange_cb(void* user, const uint64_t* mine, uint64_t* all, uint32_t count) {
+    return static_cast<Rendezvous*>(user)->allgather(mine, all, count);
+}
+
+}  // namespace
 
 int main(int argc, char* argv[]) {
     const auto start = std::chrono::steady_clock::now();
@@ -54,12 +224,30 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "Invalid operation: %s. Please use 'compress' or 'decompress'.\n", operation.c_str());
         return 1;
     }
+    if (world_rank < 0 || world_size < 1 || world_rank >= world_size) { fprintf(stderr, "bad rank %d of %d\n", world_rank, world_size); return 1; }
     if (world_rank == 0) {   // main.cpp:105-129
         struct stat st {};
         if (stat(source_path.c_str(), &st) != 0) { fprintf(stderr, "Source path does not exist.\n"); return 1; }
         if (stat(output_path.c_str(), &st) != 0) {
             if (mkdir(output_path.c_str(), 0777) == -1) { perror("Failed to create output directory"); return 1; }
         } else if (!S_ISDIR(st.st_mode)) { fprintf(stderr, "Output path is not a directory.\n"); return 1; }
+    }
+
+    Rendezvous rv;
+    rv.dir = output_path; rv.rank = world_rank; rv.world = world_size;
+    {
+        const char* id = getenv("ZWZ_RUN_ID");
+        const long parent = (long)getppid();
+        rv.stem = ".zwz_" + operation + "_" + (id && *id ? std::string(id) : "p" + std::to_string(parent) + "s" + start_time_of(parent));
+        rv.nonce = std::to_string((long)getpid()) + "s" + start_time_of((long)getpid());
+        if (world_rank == 0) rv.nonce0 = rv.nonce;
+        if (const char* t = getenv("ZWZ_RENDEZVOUS_TIMEOUT")) rv.timeout_s = atof(t);
+    }
+    if (world_size > 1 && world_rank != 0) {          // (<dst> exists once rank 0 is past its checks: MPI_Barrier, main.cpp:131)
+        const double t0 = now_s();
+        struct stat st {};
+        while (stat(output_path.c_str(), &st) != 0 && now_s() - t0 < rv.timeout_s) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        rv.hello();
     }
 
     int device_count = 0;
@@ -70,51 +258,46 @@ int main(int argc, char* argv[]) {
     const bool trace = getenv("ZWZ_VERBOSE") != nullptr;
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); };
     if (trace) fprintf(stderr, "zwz: context ready at %.3f s\n", since());
-    if (rc != ZWZ_OK) { fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error()); return 2; }
+    if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
-    const std::string tag = output_path + "/.zwz_" + operation;
     if (operation == "compress") {
         char record[4096] = "";
         if (const char* fr = getenv("ZWZ_FILE_RECORD")) snprintf(record, sizeof record, "%s", fr);
         if (world_rank == 0) {
             printf("Compressing folder: %s\n", source_path.c_str());
-            if (!record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
+            if (rc == ZWZ_OK && !record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
             printf("File record saved location: %s\n", record);
             if (trace) fprintf(stderr, "zwz: file list ready at %.3f s\n", since());
-            if (world_size > 1) { FILE* f = fopen((tag + "_list").c_str(), "w"); if (f) { fputs(record, f); fclose(f); } touch(tag + "_list_ready"); }
-        } else {   // the reference broadcasts the record path (main.cpp:24-39)
-            if (!wait_for(tag + "_list_ready", 600)) { fprintf(stderr, "rank %d: no file list from rank 0\n", world_rank); return 3; }
-            FILE* f = fopen((tag + "_list").c_str(), "r");
-            if (!f || !fgets(record, sizeof record, f)) { fprintf(stderr, "rank %d: cannot read list path\n", world_rank); return 3; }
-            fclose(f);
+            if (world_size > 1) { rv.payload = record; if (!rv.publish_to_all()) fprintf(stderr, "rank 0: not every rank announced itself; going on\n"); }
+        } else if (world_size > 1) {   // the reference broadcasts the record path (main.cpp:24-39)
+            if (!rv.accept()) { fprintf(stderr, "rank %d: no file list from rank 0\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
+            else snprintf(record, sizeof record, "%s", rv.payload.c_str());
         }
         if (rc == ZWZ_OK) {
             printf("file_record: %s\n", record);
             if (world_rank < zwz_count_non_empty_lines(record)) rc = zwz_compress_dir(ctx, source_path.c_str(), output_path.c_str(), record, world_rank, world_size);
             else printf("Rank: %d - No file to compress\n", world_rank);
         }
-    } else if (world_rank == 0) {   // main.cpp:61-68: decompression is a single-rank job
-        if (world_size > 1) printf("Decompression is not supported in MPI parallel mode.\nOnly use one process to decompress.\n");
+    } else {
+        // The reference decodes on rank 0 only (main.cpp:61-68).  Here every rank takes its share: whole shards round-robin,
+        // or record ranges of a shard when there are fewer shards than ranks (zwz_decompress_dir_ranked).
+        if (world_size > 1) {
+            if (world_rank == 0) { if (!rv.publish_to_all()) { fprintf(stderr, "rank 0: not every rank announced itself\n"); if (rc == ZWZ_OK) rc = 3; } }
+            else if (!rv.accept()) { fprintf(stderr, "rank %d: rank 0 never showed up\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
+        }
         int bad = 0;
-        rc = zwz_decompress_dir(ctx, source_path.c_str(), output_path.c_str(), &bad);
+        if (rc == ZWZ_OK) rc = zwz_decompress_dir_ranked(ctx, source_path.c_str(), output_path.c_str(), world_rank, world_size, world_size > 1 ? exchange_cb : nullptr, &rv, &bad);
     }
     if (trace) fprintf(stderr, "zwz: %s done at %.3f s\n", operation.c_str(), since());
+    if (rc != ZWZ_OK && rc != 3) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
     zwz_ctx_destroy(ctx);
     if (trace) fprintf(stderr, "zwz: context destroyed at %.3f s\n", since());
-    if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
-    if (world_size > 1) {   // MPI_Barrier (main.cpp:144)
-        touch(tag + "_done_" + std::to_string(world_rank));
-        if (world_rank == 0) {
-            for (int r = 0; r < world_size; r++) wait_for(tag + "_done_" + std::to_string(r), 3600);
-            for (int r = 0; r < world_size; r++) unlink((tag + "_done_" + std::to_string(r)).c_str());
-            unlink((tag + "_list").c_str()); unlink((tag + "_list_ready").c_str());
-        }
-    }
+    const int job_rc = rv.finish(rc == ZWZ_OK ? 0 : 2);   // MPI_Barrier (main.cpp:144)
     if (world_rank == 0) {   // main.cpp:148-155
         const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         printf("========================================\nOperation: %s\nProcessor Count: %d\nTime Taken: %g seconds\n"
                "========================================\n", operation.c_str(), world_size, total);
     }
-    return rc == ZWZ_OK ? 0 : 2;
+    return job_rc;
 }

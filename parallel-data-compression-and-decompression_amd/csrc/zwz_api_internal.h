@@ -15,6 +15,7 @@ struct zwz_ctx {
     void* d_stage = nullptr;
     void* h_stage = nullptr;
     uint32_t stage_chunks = 0;
+    uint32_t chunk_bytes = 0;        // raw bytes per Chunk for zwz_compress_dir; 0 = default (see chunk_bytes_for)
     bool profiling = false;
     hipEvent_t ev[zwz::kNumDeflateStages + 1] = {};
     hipEvent_t ev_inf[2] = {};

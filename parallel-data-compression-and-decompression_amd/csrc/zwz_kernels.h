@@ -59,7 +59,8 @@ struct BlockProbe {
 static_assert(sizeof(BlockProbe) == 32 + 640, "BlockProbe layout");
 
 constexpr uint32_t kChosenOffset = 4096;   // bytes into a chunk's link array
-static_assert(kMaxBlocks * sizeof(BlockProbe) <= kChosenOffset && kChosenOffset + 21846 * 4 <= kLinkStride * 2, "links space: probes, then chosen records");
+constexpr uint32_t kChosenCap = 21846;     // matches per chunk: fewer than 65535 / 3 + 1
+static_assert(kMaxBlocks * sizeof(BlockProbe) <= kChosenOffset && kChosenOffset + kChosenCap * 4 <= kLinkStride * 2, "links space: probes, then chosen records");
 
 struct DeflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned

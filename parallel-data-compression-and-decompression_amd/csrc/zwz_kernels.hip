@@ -2,8 +2,8 @@
 // compression.cpp:119-134 and decompression.cpp:16-36, rebuilt as a batch pipeline over HBM).
 //
 // Compress, per batch of chunks (stage -> intermediate in HBM -> next stage):
-//   lz_links    2 waves / chunk       15-bit hash + newest-first chain links (zlib's head/prev): a feeder wave
-//                                     hashes and streams, an inserter wave walks the LDS head table
+//   lz_links    9 waves / chunk       15-bit hash + newest-first chain links (zlib's head/prev): eight feeder waves
+//                                     hash and stream, an inserter wave walks the LDS head table, one exchange a step
 //   lz_match    one WG / chunk        per-position best-of-32 / best-of-128 match records; the 32 KiB history
 //                                     window (bytes + links) lives in LDS and slides tile by tile
 //   lz_parse    one wave / chunk      lazy-evaluation walk over the records, block-parallel -> symbol bit masks
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 uint32_t rank = 0;
 #pragma unroll
                 for (uint32_t b = 0; b < 8u; b++) { const uint64_t mk = __ballot(in && key == b); if (key == b) rank = rank_in(mk); }
-                if (in) perm[(uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank] = (uint16_t)q;
+                if (in) perm[((uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank) & (kTile - 1u)] = (uint16_t)q;   // (< npos by construction; masked all the same)
             }
             __syncthreads();
         }
@@ -981,7 +981,9 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         if (M) {                                     // this block's match starts are final: their records go out, selected and compact
             if ((M >> lane) & 1ull) {
                 const uint2 e = m.win[q & 127u];
-                chosen[n_match + rank_in(M)] = ((M32 >> lane) & 1ull) ? e.y : e.x;
+                // (a chunk has fewer than kChosenCap matches -- each covers three positions -- but the index is record-derived:
+                // clamped, so that no input, however wrong upstream, can reach past the chunk's own link space)
+                chosen[min(n_match + rank_in(M), kChosenCap - 1u)] = ((M32 >> lane) & 1ull) ? e.y : e.x;
             }
             n_match += (uint32_t)__popcll(M);
         }
@@ -1998,54 +2000,83 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
 // launchers
 #define ZWZ_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-// The exchange flavour of lz_links stands on a property of ds_wrxchg_rtn_b32 the ISA manual does not spell out: lanes of one
-// instruction that name the same address are served in ascending lane order (each gets what the nearest lower such lane wrote,
-// the lowest gets the old value, the highest lane's value stays).  One wave checks it on this device, over address patterns
-// from all-equal to all-distinct; a context whose device fails the check uses the read/write/read-back flavour instead.
-__global__ __launch_bounds__(64) void exchange_order_probe_kernel(uint32_t* __restrict__ violations) {
-    __shared__ uint32_t tab[256];
-    __shared__ uint32_t addr[64];
-    const uint32_t lane = threadIdx.x;
-    uint32_t bad = 0, rng = 0x9e3779b9u * (lane + 1u);
-    for (uint32_t r = 0; r < 512; r++) {
-        for (uint32_t i = lane; i < 256; i += 64) tab[i] = 0xdead0000u + i;
+// lz_links stands on a property of ds_wrxchg_rtn_b32 the ISA manual does not spell out: lanes of one instruction that name the
+// same address are served in ascending lane order (each gets what the nearest lower such lane wrote, the lowest gets the old
+// value, the highest lane's value stays).  zwz_ctx_create checks it on the device before anything else runs, under the
+// conditions lz_links creates: one workgroup of lz_links' shape on EVERY CU of every XCD (two per CU are launched, the LDS
+// lets one be resident), the real 128 KiB table, bucket patterns from all-equal to spread over the whole table, and eight
+// other waves of the workgroup streaming 16-byte reads and writes through the rest of the LDS the whole time, as the
+// feeders do.  A context whose device fails the check is not created (ZWZ_E_NO_DEVICE): there is no other flavour.
+// Per round: plain read of each lane's bucket, the exchange, plain read again; a lane must have received the value of the
+// nearest lower lane naming its bucket (else what the bucket held), and the bucket must hold the highest such lane's value.
+constexpr uint32_t kProbeRounds = 384;
+__global__ __launch_bounds__(kLinksThreads) void exchange_order_probe_kernel(uint32_t* __restrict__ violations) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];            // 32768 buckets, then the traffic area
+    constexpr uint32_t kBuckets = 32768u;
+    uint32_t* area = tab + kBuckets + 4u;                                     // 16 KiB, as lz_links' two hand-over buffers
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    for (uint32_t i = tid; i < kBuckets; i += kLinksThreads) tab[i] = 0xdead0000u + i;
+    for (uint32_t i = tid; i < 4096u; i += kLinksThreads) area[i] = i;
+    __syncthreads();
+    if (wave != 0) {
+        // feeder-like traffic: every lane streams 16-byte vectors through its own part of the area; the loop is bounded, so
+        // every wave reaches the end whatever wave 0 does
+        uint4* a4 = reinterpret_cast<uint4*>(area) + (wave - 1u) * 128u + lane;
+        uint4 v = a4[0];
+        for (uint32_t it = 0; it < 3u * kProbeRounds; it++) {
+            a4[64 * (it & 1u)] = make_uint4(v.x + it, v.y ^ it, v.z + lane, v.w);
+            v = a4[64 * ((it + 1u) & 1u)];
+        }
+        if (v.x == 0xffffffffu && v.y == 0x12345678u) violations[1] = v.z;   // (keeps the loop alive; never true in practice)
+        return;
+    }
+    typedef __attribute__((address_space(3))) uint32_t* lds_word_ptr;
+    const uint32_t tab_a = (uint32_t)(uintptr_t)(lds_word_ptr)tab;
+    uint32_t bad = 0, rng = 0x9e3779b9u * (lane + 1u) + 0x85ebca6bu * (blockIdx.x + 1u);
+    for (uint32_t r = 0; r < kProbeRounds; r++) {
         rng = rng * 1664525u + 1013904223u;
-        const uint32_t spread = 1u << (2u * (r % 5u));                           // 1, 4, 16, 64, 256 buckets
-        const uint32_t a = (rng >> 12) & (spread - 1u);
-        addr[lane] = a;
-        __syncthreads();
-        typedef __attribute__((address_space(3))) uint32_t* lds_word_ptr;
-        const uint32_t la = (uint32_t)(uintptr_t)(lds_word_ptr)&tab[a];
-        uint32_t old;
-        asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(la), "v"(0x1000u + lane) : "memory");
-        __syncthreads();
-        uint32_t want = 0xdead0000u + a, last = lane;
+        const uint32_t spread = 1u << (3u * (r % 6u));                           // 1, 8, 64, 512, 4096, 32768 buckets ...
+        const uint32_t base = (0x9e3779b1u * (r + 17u * blockIdx.x)) & (kBuckets - 1u) & ~(spread - 1u);   // ... anywhere in the table
+        const uint32_t a = base + ((rng >> 11) & (spread - 1u));
+        const uint32_t la = tab_a + 4u * a, mine = 0x10000u * (r + 1u) + lane;
+        uint32_t pre, old, post;
+        asm volatile("ds_read_b32 %0, %3\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "ds_wrxchg_rtn_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "ds_read_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(pre), "=&v"(old), "=&v"(post) : "v"(la), "v"(mine) : "memory");
+        uint32_t want = pre, last = lane;
         for (uint32_t j = 0; j < 64; j++) {
-            if (addr[j] != a) continue;
-            if (j < lane) want = 0x1000u + j;
+            const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)j);
+            if (aj != a) continue;
+            if (j < lane) want = 0x10000u * (r + 1u) + j;
             if (j > lane) last = j;
         }
-        bad += (uint32_t)(old != want) + (uint32_t)(tab[a] != 0x1000u + last);
-        __syncthreads();
+        bad += (uint32_t)(old != want) + (uint32_t)(post != 0x10000u * (r + 1u) + last);
     }
     if (bad) atomicAdd(violations, bad);
 }
 
 hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
     uint32_t* d = nullptr;
-    uint32_t h = 1;
-    ZWZ_TRY(hipMalloc(&d, sizeof(uint32_t)));
-    hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), s);
-    if (e == hipSuccess) { hipLaunchKernelGGL(exchange_order_probe_kernel, dim3(1), dim3(64), 0, s, d); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    uint32_t h[2] = {1, 0};
+    *holds = false;
+    int dev = 0, cus = 0;
+    ZWZ_TRY(hipGetDevice(&dev));
+    ZWZ_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    ZWZ_TRY(hipMalloc(&d, 2 * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(exchange_order_probe_kernel, dim3(2u * (uint32_t)cus), dim3(kLinksThreads), kLinksLdsBytes, s, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d);
-    *holds = e == hipSuccess && h == 0;
+    *holds = e == hipSuccess && h[0] == 0;
     return e;
 }
 
 hipError_t configure_kernels() {
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(exchange_order_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
     return hipSuccess;

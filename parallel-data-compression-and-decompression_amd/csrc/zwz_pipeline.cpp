@@ -62,39 +62,60 @@ class Pool {
 public:
     struct Group { std::atomic<int> pending{0}; };
     explicit Pool(unsigned n) {
-        for (unsigned i = 0; i < n; i++) workers_.emplace_back([this] { run(); });
+        for (unsigned i = 0; i < n; i++) {
+            const bool prefers_bg = n >= 4 && i % 4 == 3;
+            try { workers_.emplace_back([this, prefers_bg] { run(prefers_bg); }); }
+            catch (const std::system_error&) { if (workers_.empty()) throw; break; }   // thread limit: run with what we have
+        }
     }
     ~Pool() {
         { std::lock_guard<std::mutex> l(m_); stop_ = true; }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
-    void submit(Group& g, std::function<void()> fn) {
+    // background = true: work nothing downstream waits for soon (whole-file MD5 of big files).  Workers take foreground
+    // tasks first, so a slice's reads never queue behind every big file's hash (each ~1.5 s per GB); one worker in four
+    // prefers background work, so hashing always makes progress.
+    void submit(Group& g, std::function<void()> fn, bool background = false) {
         g.pending.fetch_add(1);
-        { std::lock_guard<std::mutex> l(m_); q_.push_back({&g, std::move(fn)}); }
-        cv_.notify_one();
+        { std::lock_guard<std::mutex> l(m_); (background ? bg_ : q_).push_back({&g, std::move(fn)}); }
+        cv_.notify_all();
     }
     void wait(Group& g) {
         std::unique_lock<std::mutex> l(m_);
         done_cv_.wait(l, [&] { return g.pending.load() == 0; });
     }
+    bool failed(std::string* why = nullptr) {
+        std::lock_guard<std::mutex> l(m_);
+        if (why) *why = failure_;
+        return has_failure_;
+    }
 private:
+    void note_failure(const char* what) {
+        std::lock_guard<std::mutex> l(m_);
+        if (!has_failure_) { has_failure_ = true; failure_ = what ? what : ""; }
+    }
+    bool has_failure_ = false;
+    std::string failure_;
     struct Task { Group* g; std::function<void()> fn; };
-    void run() {
+    void run(bool prefers_bg) {
         for (;;) {
             Task t;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return;
-                t = std::move(q_.front()); q_.pop_front();
+                cv_.wait(l, [&] { return stop_ || !q_.empty() || !bg_.empty(); });
+                if (q_.empty() && bg_.empty()) return;
+                std::deque<Task>& from = (q_.empty() || (prefers_bg && !bg_.empty())) ? bg_ : q_;
+                t = std::move(from.front()); from.pop_front();
             }
-            t.fn();
+            // a task that throws (std::bad_alloc in a vector, a std::filesystem error) must not unwind out of the thread:
+            // that is std::terminate -> abort() with nothing but a line on stderr.  It is recorded and the job fails.
+            try { t.fn(); } catch (const std::exception& ex) { note_failure(ex.what()); } catch (...) { note_failure("unknown exception"); }
             if (t.g->pending.fetch_sub(1) == 1) { std::lock_guard<std::mutex> l(m_); done_cv_.notify_all(); }
         }
     }
     std::vector<std::thread> workers_;
-    std::deque<Task> q_;
+    std::deque<Task> q_, bg_;
     std::mutex m_;
     std::condition_variable cv_, done_cv_;
     bool stop_ = false;
@@ -157,12 +178,69 @@ void free_slices(Slices& s) {
     if (s.md5_dev) (void)hipFree(s.md5_dev);
 }
 
+// Waits for every listed task group when its scope is left, however that happens: tasks capture the enclosing function's
+// locals by reference, so nothing may still be running when those locals go (declared last = destroyed first).
+struct Drain {
+    Pool& pool; std::vector<Pool::Group*> groups;
+    ~Drain() { for (Pool::Group* g : groups) pool.wait(*g); }
+};
+
+// Raw bytes per Chunk.  process.hpp:12 fixes 65535 and the shards are bit-exact only with it (the default).  SURVEY.md
+// section 8 f4, opt-in and never default: ZWZ_LOSSLESS=1 cuts files every 65504 bytes instead -- the largest size whose level-6
+// stream always fits the reference's 65535-byte payload buffer (stored worst case: 2 + 5 blocks x 5 + 65504 + 4), so no
+// chunk is ever truncated and the round trip is exact; ZWZ_CHUNK_SIZE=<n <= 65535> sets any other size.  The container is
+// unchanged and the reference's own decoder reads such shards (it takes any chunk that decodes to <= 65535 bytes).
+uint32_t chunk_bytes_for(const zwz_ctx* c) {
+    if (c->chunk_bytes) return c->chunk_bytes;
+    if (const char* v = getenv("ZWZ_CHUNK_SIZE")) { const long n = atol(v); if (n >= 1 && n <= (long)ZWZ_CHUNK_SIZE) return (uint32_t)n; }
+    if (const char* v = getenv("ZWZ_LOSSLESS")) if (*v && *v != '0') return ZWZ_LOSSLESS_CHUNK_SIZE;
+    return ZWZ_CHUNK_SIZE;
+}
+
+int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, const char* file_record, int rank, int nranks);
+int decompress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, int rank, int nranks, zwz_allgather_u64_fn exchange,
+                        void* user, int* md5_mismatches);
+
+// No exception crosses the C ABI (include/zwz.h): anything thrown below an entry point becomes a status code.
+template <class F> int guarded(const char* what, F&& body) {
+    try { return body(); }
+    catch (const std::bad_alloc&) { set_error("%s: out of host memory", what); return ZWZ_E_NOMEM; }
+    catch (const std::exception& ex) { set_error("%s: %s", what, ex.what()); return ZWZ_E_IO; }
+    catch (...) { set_error("%s: unknown exception", what); return ZWZ_E_IO; }
+}
+
 }  // namespace
 
 extern "C" {
 
 int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const char* file_record, int rank, int nranks) {
     if (!c || !src_dir || !dst_dir || !file_record || rank < 0 || nranks <= 0) return ZWZ_E_INVALID;
+    return guarded("zwz_compress_dir", [&] { return compress_dir_impl(c, src_dir, dst_dir, file_record, rank, nranks); });
+}
+
+int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int* md5_mismatches) {
+    return zwz_decompress_dir_ranked(c, src_dir, dst_dir, 0, 1, nullptr, nullptr, md5_mismatches);
+}
+
+int zwz_decompress_dir_ranked(zwz_ctx* c, const char* src_dir, const char* dst_dir, int rank, int nranks, zwz_allgather_u64_fn exchange,
+                              void* user, int* md5_mismatches) {
+    if (!c || !src_dir || !dst_dir || rank < 0 || nranks <= 0 || rank >= nranks) return ZWZ_E_INVALID;
+    if (md5_mismatches) *md5_mismatches = 0;
+    return guarded("zwz_decompress_dir", [&] { return decompress_dir_impl(c, src_dir, dst_dir, rank, nranks, exchange, user, md5_mismatches); });
+}
+
+int zwz_ctx_set_chunk_size(zwz_ctx* c, uint32_t bytes) {
+    if (!c || bytes > ZWZ_CHUNK_SIZE) return ZWZ_E_INVALID;
+    c->chunk_bytes = bytes;
+    return ZWZ_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, const char* file_record, int rank, int nranks) {
+    const uint32_t chunk_bytes = chunk_bytes_for(c);
     const auto t_entry = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {          // ZWZ_VERBOSE: the pipeline's own timeline
         if (verbose()) fprintf(stderr, "zwz: [%.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(), what);
@@ -209,7 +287,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         pool.wait(stat_group);
         for (File& f : cand) {                     // in list order, like the reference's producer
             if (!f.ok) { fprintf(stderr, "Error opening source file: \"%s\"\n", f.full.c_str()); continue; }
-            f.nchunks = (uint32_t)(f.size / ZWZ_CHUNK_SIZE) + 1;   // a short (possibly empty) read ends the file (:52-58)
+            f.nchunks = (uint32_t)(f.size / chunk_bytes) + 1;   // a short (possibly empty) read ends the file (:52-58)
             f.first_chunk = (uint32_t)total_chunks;
             total_chunks += f.nchunks;
             files.push_back(std::move(f));
@@ -236,6 +314,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
     const uint32_t nslices = (T + cap - 1) / cap;
 
     Pool::Group md5_group, read_group[2], write_group;
+    Drain drain{pool, {&md5_group, &read_group[0], &read_group[1], &write_group}};
     // chunk g -> (file, chunk index in file): files are laid out back to back
     auto file_of = [&](uint32_t g) -> uint32_t {
         uint32_t lo = 0, hi = (uint32_t)files.size() - 1;
@@ -291,8 +370,8 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
                     for (uint32_t ci = u0; ci < u1; ci++) {
                         const uint32_t slot = ff.first_chunk + ci - g0;
                         uint8_t* dstp = sl.h_in[b] + (size_t)slot * ZWZ_DEV_STRIDE;
-                        const uint64_t off = (uint64_t)ci * ZWZ_CHUNK_SIZE;
-                        const size_t want = off < ff.size ? (size_t)std::min<uint64_t>(ZWZ_CHUNK_SIZE, ff.size - off) : 0;
+                        const uint64_t off = (uint64_t)ci * chunk_bytes;
+                        const size_t want = off < ff.size ? (size_t)std::min<uint64_t>(chunk_bytes, ff.size - off) : 0;
                         size_t got = 0;
                         while (got < want && fd >= 0) {
                             ssize_t k = pread(fd, dstp + got, want - got, (off_t)(off + got));
@@ -319,7 +398,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
     for (uint32_t fi = 0; fi < (uint32_t)files.size(); fi++) {
         const File& f = files[fi];
         const bool whole = f.first_chunk / cap == (f.first_chunk + f.nchunks - 1) / cap;
-        if (!whole || f.nchunks > 64) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); });
+        if (!whole || f.nchunks > 64) pool.submit(md5_group, [&, fi] { hash_whole_file(fi); }, /*background=*/true);
     }
     auto launch_gpu = [&](uint32_t s) -> int {
         const int b = (int)(s & 1u);
@@ -365,7 +444,6 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
             r.path_len = (int32_t)f.rel.size(); r.payload = (int32_t)sl.h_olen[b][r.slot]; r.rel = &f.rel; r.md5 = nullptr;
             r.off = out_pos;
             out_pos += 4u + 4u + (uint64_t)r.path_len + 4u + 1u + (uint64_t)r.payload;
-            if (r.payload == (int32_t)ZWZ_CHUNK_SIZE && sl.h_len[b][r.slot] >= 65510u) truncated++;
             if (r.last) {
                 if (f.gpu_md5 >= 0) {
                     static const char* dig = "0123456789abcdef";
@@ -421,6 +499,11 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         pool.wait(write_group);                 // the slice's buffers go back to the GPU next
     };
 
+    auto count_truncated = [&](uint32_t s) {      // payloads that reached the 65535-byte cap: lossy, like the reference
+        const int b = (int)(s & 1u);
+        const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
+        for (uint32_t i = 0; i < m; i++) if (sl.h_olen[b][i] == ZWZ_CHUNK_SIZE && sl.h_len[b][i] >= 65510u) truncated++;
+    };
     // (ZWZ_VERBOSE: where the caller's thread spent its time)
     double t_read = 0, t_gpu = 0, t_write = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -436,6 +519,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         t0 = now();
         if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
         t_gpu += now() - t0;
+        if (s >= 1) count_truncated(s - 1);           // (reads h_len, which the next slice's readers are about to overwrite)
         if (s + 1 < nslices) start_read(s + 1);       // its buffers were last used by slice s-1, now complete
         t0 = now();
         if (s >= 1) write_records(s - 1);
@@ -445,7 +529,7 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
         double t0 = now();
         hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
         t_gpu += now() - t0; t0 = now();
-        if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_records(nslices - 1);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else { count_truncated(nslices - 1); write_records(nslices - 1); }
         t_write += now() - t0;
     }
     if (verbose())
@@ -462,278 +546,503 @@ int zwz_compress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, const
     if (close(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
     mark("shard closed");
     if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed or vanished while it was being read"); rc = ZWZ_E_IO; }
+    { std::string why; if (pool.failed(&why) && rc == ZWZ_OK) { set_error("a pipeline task failed: %s", why.c_str()); rc = ZWZ_E_IO; } }
     if (truncated && verbose())
         fprintf(stderr, "zwz: %u chunk payload(s) reached the reference's 65535-byte cap (lossy, like the reference)\n", truncated);
     return rc;
 }
 
-int zwz_decompress_dir(zwz_ctx* c, const char* src_dir, const char* dst_dir, int* md5_mismatches) {
-    if (!c || !src_dir || !dst_dir) return ZWZ_E_INVALID;
-    if (md5_mismatches) *md5_mismatches = 0;
+// ---- .zwz reader (decompression.cpp:45-163) ---------------------------------------------------------------------------
+struct Mapped {            // the shard is mapped, not read: records are parsed in place and payloads copied from the mapping
+    const uint8_t* p = nullptr; size_t n = 0;   // straight into pinned staging slots
+    ~Mapped() { if (p) munmap(const_cast<uint8_t*>(p), n); }
+    size_t size() const { return n; }
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+};
+struct Rec { uint64_t off; uint32_t len; int32_t seq; uint8_t last; uint32_t avail; };   // avail < len: the shard ends inside this payload
+struct FileInst {          // one output file instance: the records that get decoded into it, in decode order
+    std::string rel; std::vector<Rec> order; std::multimap<int32_t, Rec> pending; int32_t expected = 0; std::string md5; bool finalised = false;
+};
+
+// Pass 1: parse the records (decompression.cpp:65-92) and replay the reference's per-path sequencing (expected id +
+// pending heap, :119-153).  A shard that ends inside a record is damaged: everything in front of the damage is kept and
+// decoded as the reference's reader would have (it processes record after record until its stream fails): a record cut
+// inside its payload is decoded from the bytes that are there followed by zeros up to its declared length (the
+// reference reads into a zero-filled vector of that length, decompression.cpp:82-84), one cut inside its MD5 keeps the
+// partial digest (and so fails verification).  Returns false if the shard was damaged.
+bool parse_shard(const Mapped& blob, std::vector<FileInst>& insts) {
+    std::map<std::string, size_t> open_inst;
+    bool intact = true;
+    size_t p = 0;
+    while (p < blob.size()) {
+        int32_t total, path_len, seq;
+        if (p + 8 > blob.size()) { intact = false; break; }
+        memcpy(&total, &blob[p], 4); memcpy(&path_len, &blob[p + 4], 4); p += 8;
+        if (path_len < 0 || p + (size_t)path_len + 5 > blob.size()) { intact = false; break; }
+        std::string rel(reinterpret_cast<const char*>(&blob[p]), (size_t)path_len); p += (size_t)path_len;
+        memcpy(&seq, &blob[p], 4); p += 4;
+        const uint8_t last = blob[p++];
+        int64_t plen = (int64_t)total - (4 + path_len + 4 + 1);
+        if (plen < 0 || plen > (int64_t)ZWZ_CHUNK_SIZE) { intact = false; break; }     // (the reference's CompressedChunk holds 65535 bytes)
+        uint32_t avail = (uint32_t)plen;
+        if (p + (size_t)plen > blob.size()) { intact = false; avail = (uint32_t)(blob.size() - p); }
+        Rec r{(uint64_t)p, (uint32_t)plen, seq, last, avail};
+        p += (size_t)avail;
+        std::string md5;
+        if (last) {
+            const size_t have = std::min<size_t>(ZWZ_MD5_HEX_LEN, blob.size() - p);
+            md5.assign(reinterpret_cast<const char*>(&blob[p]), have);
+            md5.resize(ZWZ_MD5_HEX_LEN, '\0');
+            if (have < ZWZ_MD5_HEX_LEN) intact = false;
+            p += have;
+        }
+        auto it = open_inst.find(rel);
+        if (it == open_inst.end()) { insts.push_back(FileInst{}); insts.back().rel = rel; it = open_inst.emplace(rel, insts.size() - 1).first; }
+        FileInst& fi = insts[it->second];
+        if (last) fi.md5 = md5;
+        if (fi.expected == seq) {
+            fi.order.push_back(r); fi.expected++;
+            for (auto pit = fi.pending.find(fi.expected); pit != fi.pending.end(); pit = fi.pending.find(fi.expected)) {
+                fi.order.push_back(pit->second); fi.pending.erase(pit); fi.expected++;
+            }
+            if (last && fi.expected == seq + 1 && fi.pending.empty()) { fi.finalised = true; open_inst.erase(it); }
+        } else {
+            fi.pending.emplace(seq, r);
+        }
+        if (!intact) break;
+    }
+    return intact;
+}
+
+int map_shard(const std::string& shard, Mapped& blob, bool& opened) {
+    opened = false;
+    const int fd = open(shard.c_str(), O_RDONLY);
+    if (fd < 0) { fprintf(stderr, "Error opening file: %s\n", shard.c_str()); return ZWZ_OK; }   // decompression.cpp:47-50
+    opened = true;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); set_error("cannot stat %s", shard.c_str()); return ZWZ_E_IO; }
+    if (sb.st_size > 0) {
+        void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); set_error("cannot map %s", shard.c_str()); return ZWZ_E_IO; }
+        blob.p = static_cast<const uint8_t*>(m); blob.n = (size_t)sb.st_size;
+        (void)madvise(m, blob.n, MADV_WILLNEED);
+    }
+    close(fd);
+    return ZWZ_OK;
+}
+
+struct Job { uint32_t inst; Rec r; };
+
+// What both decode modes share: output files, MD5 verification, the reference's messages.
+struct DecodeSink {
+    const char* dst_dir; std::vector<FileInst>& insts; std::atomic<int>& mismatches; std::mutex& log_mutex;
+    std::string path_of(uint32_t inst) const { return std::string(dst_dir) + "/" + insts[inst].rel; }
+    void make_parent(const std::string& file_path) const {
+        std::error_code ec;
+        fs::path dir = fs::path(file_path).parent_path();
+        if (!dir.empty() && !fs::exists(dir, ec)) fs::create_directories(dir, ec);
+    }
+    void verdict(uint32_t inst, const char* hex) const {         // decompression.cpp:132-149
+        const FileInst& fi = insts[inst];
+        const std::string file_path = path_of(inst);
+        std::lock_guard<std::mutex> l(log_mutex);
+        if (fi.finalised) {
+            if (fi.md5 != hex) {
+                mismatches.fetch_add(1);
+                fprintf(stderr, "MD5 mismatch for file: %s\n", file_path.c_str());
+                if (verbose()) printf("Expected MD5: %s\nCalculated MD5: %s\n", fi.md5.c_str(), hex);
+            } else if (verbose()) printf("MD5 match for file: %s\n", file_path.c_str());
+        } else if (!fi.pending.empty()) {
+            fprintf(stderr, "Warning: pending chunks remaining for file: %s\n", fi.rel.c_str());
+        }
+    }
+    void hash_from_disk(uint32_t inst) const {                   // md5_of_file(), verification.cpp:6-30
+        Md5 m;
+        const std::string file_path = path_of(inst);
+        const int fd = open(file_path.c_str(), O_RDONLY);
+        std::vector<uint8_t> buf(1 << 20);
+        for (uint64_t off = 0; fd >= 0;) {
+            ssize_t k = pread(fd, buf.data(), buf.size(), (off_t)off);
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) break;
+            m.update(buf.data(), (size_t)k); off += (uint64_t)k;
+        }
+        if (fd >= 0) close(fd);
+        char hex[33]; m.hex(hex);
+        verdict(inst, hex);
+    }
+};
+
+// pwritev of a run of decoded chunks at a known file offset
+void pwrite_chunks(int fd, uint64_t off, std::vector<struct iovec>& iov) {
+    size_t k = 0;
+    while (k < iov.size()) {
+        if (iov[k].iov_len == 0) { k++; continue; }
+        ssize_t w = pwritev(fd, iov.data() + k, (int)std::min<size_t>(512, iov.size() - k), (off_t)off);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) break;                            // (a short file then fails its MD5 check)
+        off += (uint64_t)w;
+        size_t left = (size_t)w;
+        while (left) {
+            if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+            else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
+        }
+    }
+}
+
+// ---- one whole shard on this rank: all scheduled records, slice by slice, double-buffered; files are written and hashed by
+// the pool, one task per file per slice (slices of a file run in order)
+int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<FileInst>& insts, DecodeSink& sink) {
+    std::vector<Job> jobs;
+    for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
+    struct OutState { FILE* f = nullptr; int fd = -1; uint64_t written = 0; Md5 md5; uint32_t remaining = 0; bool failed = false; bool deferred = false; };
+    std::vector<OutState> outs(insts.size());
+    for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
+    const uint32_t T = (uint32_t)jobs.size();
+    const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
+    Slices sl;
+    int rc = make_slices(c, cap, sl);
+    if (rc) return rc;
+    const uint32_t nslices = (T + cap - 1) / cap;
+    Pool::Group fill_group[2], write_group, md5_group;
+    Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group, &md5_group}};
+    // MD5 is one sequential stream per file (~0.65 GB/s).  A file decoded within one slice is hashed by the task that
+    // writes it, from the staging buffer; a file that spans slices would hold every slice back for its hash (three
+    // 384 MiB files: 2.1 s, slower than the reference), so it is hashed afterwards, from the file just written, by a
+    // task of its own that runs beside the slices of the files behind it.
+    {
+        uint32_t g = 0;
+        for (uint32_t i = 0; i < insts.size(); i++) {
+            const uint32_t k = (uint32_t)insts[i].order.size();
+            if (k) outs[i].deferred = g / cap != (g + k - 1) / cap;
+            g += k;
+        }
+    }
+    auto open_out = [&](uint32_t inst) {
+        const std::string file_path = sink.path_of(inst);
+        sink.make_parent(file_path);
+        outs[inst].f = fopen(file_path.c_str(), "wb");
+        if (!outs[inst].f) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); outs[inst].failed = true; }
+    };
+    auto finish_out = [&](uint32_t inst) {
+        OutState& o = outs[inst];
+        if (o.f) { fclose(o.f); o.f = nullptr; }
+        char hex[33];
+        o.md5.hex(hex);
+        sink.verdict(inst, hex);
+    };
+    auto start_fill = [&](uint32_t s) {
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
+            const uint32_t u1 = std::min(g1, u0 + 256);
+            pool.submit(fill_group[b], [&, b, g0, u0, u1] {
+                for (uint32_t g = u0; g < u1; g++) {
+                    const Rec& r = jobs[g].r;
+                    uint8_t* slot = sl.h_in[b] + (size_t)(g - g0) * ZWZ_DEV_STRIDE;
+                    memcpy(slot, &blob[r.off], r.avail);
+                    if (r.avail < r.len) memset(slot + r.avail, 0, r.len - r.avail);
+                    sl.h_off[b][g - g0] = (uint64_t)(g - g0) * ZWZ_DEV_STRIDE; sl.h_len[b][g - g0] = r.len;
+                }
+            });
+        }
+    };
+    auto launch_gpu = [&](uint32_t s) -> int {
+        const int b = (int)(s & 1u);
+        const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
+        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        int r = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b], sl.d_st[b]);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(sl.done[b], c->stream));
+        return ZWZ_OK;
+    };
+    // One task per file that has records in this slice -- a file decoded within one slice is written (stdio) and hashed
+    // by it.  A file that spans slices is written with pwritev at offsets laid out here, 128 records a task, and
+    // hashed afterwards from the file (see `deferred` above).
+    auto write_slice = [&](uint32_t s) {
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        std::vector<uint32_t> finished;          // spanning files whose last record is in this slice
+        uint32_t g = g0;
+        while (g < g1) {
+            uint32_t e = g;
+            while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
+            const uint32_t inst = jobs[g].inst, a0 = g, a1 = e;
+            OutState& os = outs[inst];
+            if (!os.deferred) {
+                pool.submit(write_group, [&, b, g0, inst, a0, a1] {
+                    OutState& o = outs[inst];
+                    if (!o.f && !o.failed) open_out(inst);
+                    for (uint32_t k = a0; k < a1; k++) {
+                        const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
+                        const uint32_t n = sl.h_olen[b][k - g0];
+                        if (o.f) fwrite(src, 1, n, o.f);
+                        o.md5.update(src, n);
+                    }
+                    o.remaining -= a1 - a0;
+                    if (o.remaining == 0) finish_out(inst);
+                });
+            } else {
+                if (os.fd < 0 && !os.failed) {
+                    const std::string file_path = sink.path_of(inst);
+                    sink.make_parent(file_path);
+                    os.fd = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+                    if (os.fd < 0) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); os.failed = true; }
+                }
+                for (uint32_t r0 = a0; r0 < a1 && os.fd >= 0; r0 += 128) {
+                    const uint32_t r1 = std::min(a1, r0 + 128);
+                    const uint64_t off0 = os.written;
+                    uint64_t bytes = 0;
+                    for (uint32_t k = r0; k < r1; k++) bytes += sl.h_olen[b][k - g0];
+                    os.written += bytes;
+                    const int fd = os.fd;
+                    pool.submit(write_group, [&, b, g0, fd, r0, r1, off0] {
+                        std::vector<struct iovec> iov;
+                        for (uint32_t k = r0; k < r1; k++)
+                            if (sl.h_olen[b][k - g0]) iov.push_back({sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE, (size_t)sl.h_olen[b][k - g0]});
+                        pwrite_chunks(fd, off0, iov);
+                    });
+                }
+                os.remaining -= a1 - a0;
+                if (os.remaining == 0) finished.push_back(inst);
+            }
+            g = e;
+        }
+        pool.wait(write_group);              // the next slice of a file must follow this one
+        for (uint32_t inst : finished) {
+            OutState& o = outs[inst];
+            if (o.fd >= 0) { close(o.fd); o.fd = -1; }
+            pool.submit(md5_group, [&sink, inst] { sink.hash_from_disk(inst); }, /*background=*/true);
+        }
+    };
+
+    if (nslices) start_fill(0);
+    for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+        pool.wait(fill_group[s & 1]);
+        rc = launch_gpu(s);
+        if (rc) break;
+        if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
+        if (s + 1 < nslices) start_fill(s + 1);
+        if (s >= 1) write_slice(s - 1);
+    }
+    if (rc == ZWZ_OK && nslices) {
+        hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_slice(nslices - 1);
+    }
+    pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(md5_group);
+    (void)hipStreamSynchronize(c->stream);
+    free_slices(sl);
+    // instances that never received a decodable record still get created (the reference opens on the first record of a path)
+    for (uint32_t i = 0; i < insts.size(); i++)
+        if (insts[i].order.empty()) { open_out(i); finish_out(i); }
+    return rc;
+}
+
+// ---- one shard split over all ranks (the reference decodes a shard serially on one thread,
+// decompression.cpp:65-154).  Every rank parses the headers (cheap) and so holds the same schedule; rank r takes the r-th
+// contiguous range of it, inflates the range into device memory, and only then learns where its bytes go: a chunk's place in
+// its file is the sum of the DECODED lengths in front of it (truncated chunks decode short), so the ranks all-gather, per
+// rank, the bytes it decoded for the first and for the last file of its range -- the only files it can share with a
+// neighbour.  Then every rank writes its range at its offsets; a second exchange is the barrier after which the rank
+// holding a shared file's last record verifies its MD5.  <dst> must be one file system for all ranks (as for the
+// reference, whose ranks share everything).
+int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<FileInst>& insts, DecodeSink& sink, int rank, int nranks,
+                       zwz_allgather_u64_fn exchange, void* user) {
+    std::vector<Job> jobs;
+    for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
+    const uint64_t T = jobs.size();
+    const uint32_t j0 = (uint32_t)(T * (uint64_t)rank / (uint64_t)nranks), j1 = (uint32_t)(T * (uint64_t)(rank + 1) / (uint64_t)nranks);
+    const uint32_t n = j1 - j0;
+    int rc = ZWZ_OK;
+    uint8_t* d_big = nullptr; uint32_t* d_lens = nullptr; uint32_t* d_stat = nullptr;
+    std::vector<uint32_t> lens(n);
+    Slices sl;
+    bool have_slices = false;
+    const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, n ? (n + 1) / 2 + 1 : 1u)));
+    const uint32_t nslices = (n + cap - 1) / cap;
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(c->stream);
+        if (have_slices) free_slices(sl);
+        if (d_big) (void)hipFree(d_big);
+        if (d_lens) (void)hipFree(d_lens);
+        if (d_stat) (void)hipFree(d_stat);
+    };
+    if (n) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)n * ZWZ_DEV_STRIDE);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), (size_t)n * sizeof(uint32_t));
+        if (e != hipSuccess) { cleanup(); set_error("record range of %u chunks does not fit device memory: %s", n, hipGetErrorString(e)); return ZWZ_E_NOMEM; }
+        rc = make_slices(c, cap, sl);
+        if (rc) { cleanup(); return rc; }
+        have_slices = true;
+    }
+    Pool::Group fill_group[2], write_group;
+    Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group}};
+    // ---- phase 1: payloads in, range inflated into d_big, only the decoded lengths come back
+    auto start_fill = [&](uint32_t s) {
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
+        for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
+            const uint32_t u1 = std::min(g1, u0 + 256);
+            pool.submit(fill_group[b], [&, b, g0, u0, u1] {
+                for (uint32_t g = u0; g < u1; g++) {
+                    const Rec& r = jobs[j0 + g].r;
+                    uint8_t* slot = sl.h_in[b] + (size_t)(g - g0) * ZWZ_DEV_STRIDE;
+                    memcpy(slot, &blob[r.off], r.avail);
+                    if (r.avail < r.len) memset(slot + r.avail, 0, r.len - r.avail);
+                    sl.h_off[b][g - g0] = (uint64_t)(g - g0) * ZWZ_DEV_STRIDE; sl.h_len[b][g - g0] = r.len;
+                }
+            });
+        }
+    };
+    if (nslices) start_fill(0);
+    for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+        const int b = (int)(s & 1u);
+        const uint32_t g0 = s * cap, m = std::min(n, g0 + cap) - g0;
+        pool.wait(fill_group[b]);
+        hipError_t e = hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync"); break; }
+        rc = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, d_big + (size_t)g0 * ZWZ_DEV_STRIDE, ZWZ_DEV_STRIDE, d_lens + g0, d_stat + g0);
+        if (rc) break;
+        e = hipEventRecord(sl.done[b], c->stream);
+        if (e == hipSuccess && s >= 1) e = hipEventSynchronize(sl.done[(s - 1) & 1]);      // the other buffer pair is free again
+        if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
+        if (s + 1 < nslices) start_fill(s + 1);
+    }
+    pool.wait(fill_group[0]); pool.wait(fill_group[1]);
+    if (rc == ZWZ_OK && n) {
+        hipError_t e = hipMemcpyAsync(lens.data(), d_lens, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "decoded lengths");
+    }
+    // Files are created (and truncated) by the rank that holds their first record, BEFORE the exchange: a rank that joins a
+    // file further in opens it only afterwards, so no write can be lost to a late O_TRUNC.
+    std::vector<int> fds(insts.size(), -1);
+    for (uint32_t g = j0; g < j1 && rc == ZWZ_OK; g++) {
+        const uint32_t inst = jobs[g].inst;
+        if (g != 0 && jobs[g - 1].inst == inst) continue;
+        const std::string file_path = sink.path_of(inst);
+        sink.make_parent(file_path);
+        fds[inst] = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fds[inst] < 0) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); }
+    }
+    // ---- exchange: (first file, bytes decoded into it, last file, bytes decoded into it, status) per rank.  Every rank
+    // takes part even after a local failure, so that nobody waits for a rank that has given up.
+    constexpr uint32_t kFields = 5;
+    const uint64_t kNoFile = ~0ull;
+    uint64_t mine[kFields] = {kNoFile, 0, kNoFile, 0, (uint64_t)(rc != ZWZ_OK)};
+    if (n && rc == ZWZ_OK) {
+        mine[0] = jobs[j0].inst; mine[2] = jobs[j1 - 1].inst;
+        for (uint32_t g = 0; g < n && jobs[j0 + g].inst == mine[0]; g++) mine[1] += lens[g];
+        for (uint32_t g = n; g-- > 0 && jobs[j0 + g].inst == mine[2];) mine[3] += lens[g];
+    }
+    std::vector<uint64_t> all((size_t)nranks * kFields);
+    if (exchange(user, mine, all.data(), kFields) != 0) { cleanup(); set_error("rank exchange failed"); return ZWZ_E_IO; }
+    for (int r = 0; r < nranks; r++) if (all[(size_t)r * kFields + 4]) { if (rc == ZWZ_OK) { set_error("rank %d failed while decoding its record range", r); rc = ZWZ_E_IO; } }
+    // ---- phase 2: this rank's bytes to their places
+    std::vector<uint64_t> cursor(insts.size(), 0);
+    if (rc == ZWZ_OK && n) {
+        for (int r = 0; r < rank; r++)                      // what earlier ranks decoded into the file my range starts in
+            if (all[(size_t)r * kFields + 2] == mine[0]) cursor[mine[0]] += all[(size_t)r * kFields + 3];
+        for (uint32_t s = 0; s < nslices; s++) {
+            const int b = (int)(s & 1u);
+            const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
+            hipError_t e = hipMemcpyAsync(sl.h_out[b], d_big + (size_t)g0 * ZWZ_DEV_STRIDE, (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "decoded range to host"); break; }
+            if (s >= 1) pool.wait(write_group);             // (two buffer pairs: the copy above overlapped the previous slice's writes)
+            for (uint32_t r0 = g0; r0 < g1;) {
+                const uint32_t inst = jobs[j0 + r0].inst;
+                uint32_t r1 = r0;
+                uint64_t bytes = 0;
+                while (r1 < g1 && r1 - r0 < 128 && jobs[j0 + r1].inst == inst) bytes += lens[r1++];
+                const bool joins = r0 == 0 && j0 != 0 && jobs[j0 - 1].inst == inst;     // a file begun by an earlier rank
+                if (fds[inst] < 0 && joins) fds[inst] = open(sink.path_of(inst).c_str(), O_WRONLY, 0666);
+                const uint64_t off0 = cursor[inst];
+                cursor[inst] += bytes;
+                const int fd = fds[inst];
+                if (fd >= 0)
+                    pool.submit(write_group, [&, b, g0, fd, r0, r1, off0] {
+                        std::vector<struct iovec> iov;
+                        for (uint32_t k = r0; k < r1; k++) if (lens[k]) iov.push_back({sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE, (size_t)lens[k]});
+                        pwrite_chunks(fd, off0, iov);
+                    });
+                r0 = r1;
+            }
+        }
+        pool.wait(write_group);
+    }
+    for (int fd : fds) if (fd >= 0) close(fd);
+    cleanup();
+    // ---- barrier, then verification by whoever holds a file's last record
+    uint64_t flag[1] = {(uint64_t)(rc != ZWZ_OK)};
+    std::vector<uint64_t> flags((size_t)nranks);
+    if (exchange(user, flag, flags.data(), 1) != 0) { set_error("rank exchange failed"); return ZWZ_E_IO; }
+    for (int r = 0; r < nranks; r++) if (flags[(size_t)r] && rc == ZWZ_OK) { set_error("rank %d failed while writing its record range", r); rc = ZWZ_E_IO; }
+    if (rc == ZWZ_OK) {
+        Pool::Group md5_group;
+        Drain d2{pool, {&md5_group}};
+        uint32_t prev = 0xffffffffu;
+        for (uint32_t g = j0; g < j1; g++) {
+            const uint32_t inst = jobs[g].inst;
+            const bool last_of_file = g + 1 == T || jobs[g + 1].inst != inst;
+            if (last_of_file && inst != prev) pool.submit(md5_group, [&sink, inst] { sink.hash_from_disk(inst); });
+            if (last_of_file) prev = inst;
+        }
+        if (rank == 0)       // files without a decodable record are still created (the reference opens on the first record of a path)
+            for (uint32_t i = 0; i < insts.size(); i++)
+                if (insts[i].order.empty()) {
+                    const std::string file_path = sink.path_of(i);
+                    sink.make_parent(file_path);
+                    if (FILE* f = fopen(file_path.c_str(), "wb")) fclose(f);
+                    Md5 m; char hex[33]; m.hex(hex);
+                    sink.verdict(i, hex);
+                }
+        pool.wait(md5_group);
+    }
+    return rc;
+}
+
+int decompress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, int rank, int nranks, zwz_allgather_u64_fn exchange,
+                        void* user, int* md5_mismatches) {
     std::vector<std::string> shards;
-    try {
-        for (const auto& e : fs::directory_iterator(src_dir))   // decompression.cpp:168-172
-            if (e.path().extension() == ".zwz") shards.push_back(e.path().string());
-    } catch (const std::exception& ex) { set_error("%s", ex.what()); return ZWZ_E_IO; }
+    for (const auto& e : fs::directory_iterator(src_dir))   // decompression.cpp:168-172
+        if (e.path().extension() == ".zwz") shards.push_back(e.path().string());
+    std::sort(shards.begin(), shards.end());                // every rank must see the same order
+    // Shard j -> rank j mod N when there is a shard for every rank (the reference: one OpenMP thread per shard,
+    // decompression.cpp:174-177); fewer shards than ranks (BASELINE config 5: ONE shard) are each split over all ranks.
+    const bool split = nranks > 1 && shards.size() < (size_t)nranks;
+    if (split && !exchange) { set_error("%zu shard(s) for %d ranks needs the rank exchange callback", shards.size(), nranks); return ZWZ_E_INVALID; }
 
     HIPCHK(hipSetDevice(c->device));
     Pool pool(host_threads());
     std::atomic<int> mismatches{0};
     std::mutex log_mutex;
     int rc = ZWZ_OK;
-
-    for (const std::string& shard : shards) {
-        // ---- pass 1: parse records (decompression.cpp:65-92) and replay the reference's per-path
-        // sequencing (expected id + pending heap, :119-153): per output file instance, the ordered
-        // list of records that get decoded into it.
-        int fd = open(shard.c_str(), O_RDONLY);
-        if (fd < 0) { fprintf(stderr, "Error opening file: %s\n", shard.c_str()); continue; }
-        struct stat sb;
-        fstat(fd, &sb);
-        // the shard is mapped, not read: the records are parsed in place and the pool copies payloads from the mapping
-        // straight into the pinned staging slots (a read() into a zero-filled vector was two serial passes over the file)
-        struct Mapped {
-            const uint8_t* p = nullptr; size_t n = 0;
-            ~Mapped() { if (p) munmap(const_cast<uint8_t*>(p), n); }
-            size_t size() const { return n; }
-            const uint8_t& operator[](size_t i) const { return p[i]; }
-        } blob;
-        if (sb.st_size > 0) {
-            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { close(fd); set_error("cannot map %s", shard.c_str()); return ZWZ_E_IO; }
-            blob.p = static_cast<const uint8_t*>(m); blob.n = (size_t)sb.st_size;
-            (void)madvise(m, blob.n, MADV_WILLNEED);
-        }
-        close(fd);
-
-        struct Rec { uint64_t off; uint32_t len; int32_t seq; uint8_t last; };
-        struct FileInst { std::string rel; std::vector<Rec> order; std::multimap<int32_t, Rec> pending; int32_t expected = 0; std::string md5; bool finalised = false; };
+    bool damaged = false;
+    for (size_t j = 0; j < shards.size(); j++) {
+        if (!split && (int)(j % (size_t)nranks) != rank) continue;
+        Mapped blob;
+        bool opened = false;
+        rc = map_shard(shards[j], blob, opened);
+        if (rc) break;
+        if (!opened && !split) continue;
         std::vector<FileInst> insts;
-        std::map<std::string, size_t> open_inst;
-        size_t p = 0;
-        while (p + 4 <= blob.size()) {
-            int32_t total, path_len, seq;
-            memcpy(&total, &blob[p], 4); p += 4;
-            if (p + 4 > blob.size()) break;
-            memcpy(&path_len, &blob[p], 4); p += 4;
-            if (path_len < 0 || p + (size_t)path_len + 5 > blob.size()) break;
-            std::string rel(reinterpret_cast<const char*>(&blob[p]), (size_t)path_len); p += (size_t)path_len;
-            memcpy(&seq, &blob[p], 4); p += 4;
-            const uint8_t last = blob[p++];
-            const int64_t plen = (int64_t)total - (4 + path_len + 4 + 1);
-            if (plen < 0 || plen > (int64_t)ZWZ_CHUNK_SIZE || p + (size_t)plen > blob.size()) { rc = ZWZ_E_FORMAT; break; }
-            Rec r{(uint64_t)p, (uint32_t)plen, seq, last};
-            p += (size_t)plen;
-            std::string md5;
-            if (last) { if (p + ZWZ_MD5_HEX_LEN > blob.size()) { rc = ZWZ_E_FORMAT; break; } md5.assign(reinterpret_cast<const char*>(&blob[p]), ZWZ_MD5_HEX_LEN); p += ZWZ_MD5_HEX_LEN; }
-            auto it = open_inst.find(rel);
-            if (it == open_inst.end()) { insts.push_back(FileInst{}); insts.back().rel = rel; it = open_inst.emplace(rel, insts.size() - 1).first; }
-            FileInst& fi = insts[it->second];
-            if (last) fi.md5 = md5;
-            if (fi.expected == seq) {
-                fi.order.push_back(r); fi.expected++;
-                for (auto pit = fi.pending.find(fi.expected); pit != fi.pending.end(); pit = fi.pending.find(fi.expected)) {
-                    fi.order.push_back(pit->second); fi.pending.erase(pit); fi.expected++;
-                }
-                if (last && fi.expected == seq + 1 && fi.pending.empty()) { fi.finalised = true; open_inst.erase(it); }
-            } else {
-                fi.pending.emplace(seq, r);
-            }
-        }
-        if (rc) { set_error("malformed shard %s", shard.c_str()); return rc; }
-
-        // ---- pass 2: all scheduled records, slice by slice, double-buffered; files are written and
-        // hashed by the pool, one task per file per slice (slices of a file run in order)
-        struct Job { uint32_t inst; Rec r; };
-        std::vector<Job> jobs;
-        for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
-        struct OutState { FILE* f = nullptr; int fd = -1; uint64_t written = 0; Md5 md5; uint32_t remaining = 0; bool failed = false; bool deferred = false; };
-        std::vector<OutState> outs(insts.size());
-        for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
-        const uint32_t T = (uint32_t)jobs.size();
-        const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
-        Slices sl;
-        rc = make_slices(c, cap, sl);
-        if (rc) return rc;
-        const uint32_t nslices = (T + cap - 1) / cap;
-        Pool::Group fill_group[2], write_group, md5_group;
-        // MD5 is one sequential stream per file (~0.65 GB/s).  A file decoded within one slice is hashed by the task that
-        // writes it, from the staging buffer; a file that spans slices would hold every slice back for its hash (three
-        // 384 MiB files: 2.1 s, slower than the reference), so it is hashed afterwards, from the file just written, by a
-        // task of its own that runs beside the slices of the files behind it.
-        {
-            uint32_t g = 0;
-            for (uint32_t i = 0; i < insts.size(); i++) {
-                const uint32_t k = (uint32_t)insts[i].order.size();
-                if (k) outs[i].deferred = g / cap != (g + k - 1) / cap;
-                g += k;
-            }
-        }
-
-        auto open_out = [&](uint32_t inst) {
-            const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
-            std::error_code ec;
-            fs::path dir = fs::path(file_path).parent_path();
-            if (!dir.empty() && !fs::exists(dir, ec)) fs::create_directories(dir, ec);
-            outs[inst].f = fopen(file_path.c_str(), "wb");
-            if (!outs[inst].f) { std::lock_guard<std::mutex> l(log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); outs[inst].failed = true; }
-        };
-        auto finish_out = [&](uint32_t inst) {
-            OutState& o = outs[inst];
-            if (o.f) { fclose(o.f); o.f = nullptr; }
-            const FileInst& fi = insts[inst];
-            const std::string file_path = std::string(dst_dir) + "/" + fi.rel;
-            std::lock_guard<std::mutex> l(log_mutex);
-            if (fi.finalised) {   // decompression.cpp:132-149
-                char hex[33];
-                o.md5.hex(hex);
-                if (fi.md5 != hex) {
-                    mismatches.fetch_add(1);
-                    fprintf(stderr, "MD5 mismatch for file: %s\n", file_path.c_str());
-                    if (verbose()) printf("Expected MD5: %s\nCalculated MD5: %s\n", fi.md5.c_str(), hex);
-                } else if (verbose()) printf("MD5 match for file: %s\n", file_path.c_str());
-            } else if (!fi.pending.empty()) {
-                fprintf(stderr, "Warning: pending chunks remaining for file: %s\n", fi.rel.c_str());
-            }
-        };
-        auto start_fill = [&](uint32_t s) {
-            const int b = (int)(s & 1u);
-            const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
-            for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
-                const uint32_t u1 = std::min(g1, u0 + 256);
-                pool.submit(fill_group[b], [&, b, g0, u0, u1] {
-                    for (uint32_t g = u0; g < u1; g++) {
-                        const Rec& r = jobs[g].r;
-                        memcpy(sl.h_in[b] + (size_t)(g - g0) * ZWZ_DEV_STRIDE, &blob[r.off], r.len);
-                        sl.h_off[b][g - g0] = (uint64_t)(g - g0) * ZWZ_DEV_STRIDE; sl.h_len[b][g - g0] = r.len;
-                    }
-                });
-            }
-        };
-        auto launch_gpu = [&](uint32_t s) -> int {
-            const int b = (int)(s & 1u);
-            const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
-            HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-            int r = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b], sl.d_st[b]);
-            if (r) return r;
-            HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipEventRecord(sl.done[b], c->stream));
-            return ZWZ_OK;
-        };
-        // One task per file that has records in this slice -- a file decoded within one slice is written (stdio) and hashed
-        // by it.  A file that spans slices is written with pwritev at offsets laid out here, 128 records a task, and
-        // hashed afterwards from the file (see `deferred` above).
-        auto write_slice = [&](uint32_t s) {
-            const int b = (int)(s & 1u);
-            const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
-            std::vector<uint32_t> finished;          // spanning files whose last record is in this slice
-            uint32_t g = g0;
-            while (g < g1) {
-                uint32_t e = g;
-                while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
-                const uint32_t inst = jobs[g].inst, a0 = g, a1 = e;
-                OutState& os = outs[inst];
-                if (!os.deferred) {
-                    pool.submit(write_group, [&, b, g0, inst, a0, a1] {
-                        OutState& o = outs[inst];
-                        if (!o.f && !o.failed) open_out(inst);
-                        for (uint32_t k = a0; k < a1; k++) {
-                            const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
-                            const uint32_t n = sl.h_olen[b][k - g0];
-                            if (o.f) fwrite(src, 1, n, o.f);
-                            o.md5.update(src, n);
-                        }
-                        o.remaining -= a1 - a0;
-                        if (o.remaining == 0) finish_out(inst);
-                    });
-                } else {
-                    if (os.fd < 0 && !os.failed) {
-                        const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
-                        std::error_code ec;
-                        fs::path dir = fs::path(file_path).parent_path();
-                        if (!dir.empty() && !fs::exists(dir, ec)) fs::create_directories(dir, ec);
-                        os.fd = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-                        if (os.fd < 0) { std::lock_guard<std::mutex> l(log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); os.failed = true; }
-                    }
-                    for (uint32_t r0 = a0; r0 < a1 && os.fd >= 0; r0 += 128) {
-                        const uint32_t r1 = std::min(a1, r0 + 128);
-                        const uint64_t off0 = os.written;
-                        uint64_t bytes = 0;
-                        for (uint32_t k = r0; k < r1; k++) bytes += sl.h_olen[b][k - g0];
-                        os.written += bytes;
-                        const int fd = os.fd;
-                        pool.submit(write_group, [&, b, g0, fd, r0, r1, off0] {
-                            std::vector<struct iovec> iov;
-                            for (uint32_t k = r0; k < r1; k++)
-                                if (sl.h_olen[b][k - g0]) iov.push_back({sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE, (size_t)sl.h_olen[b][k - g0]});
-                            uint64_t off = off0;
-                            size_t k = 0;
-                            while (k < iov.size()) {
-                                ssize_t w = pwritev(fd, iov.data() + k, (int)std::min<size_t>(512, iov.size() - k), (off_t)off);
-                                if (w < 0 && errno == EINTR) continue;
-                                if (w <= 0) break;                            // (a short file then fails its MD5 check)
-                                off += (uint64_t)w;
-                                size_t left = (size_t)w;
-                                while (left) {
-                                    if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
-                                    else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
-                                }
-                            }
-                        });
-                    }
-                    os.remaining -= a1 - a0;
-                    if (os.remaining == 0) finished.push_back(inst);
-                }
-                g = e;
-            }
-            pool.wait(write_group);              // the next slice of a file must follow this one
-            for (uint32_t inst : finished) {
-                OutState& o = outs[inst];
-                if (o.fd >= 0) { close(o.fd); o.fd = -1; }
-                pool.submit(md5_group, [&, inst] {
-                    OutState& oo = outs[inst];
-                    const std::string file_path = std::string(dst_dir) + "/" + insts[inst].rel;
-                    const int fd = open(file_path.c_str(), O_RDONLY);
-                    std::vector<uint8_t> buf(1 << 20);
-                    for (uint64_t off = 0; fd >= 0;) {
-                        ssize_t k = pread(fd, buf.data(), buf.size(), (off_t)off);
-                        if (k < 0 && errno == EINTR) continue;
-                        if (k <= 0) break;
-                        oo.md5.update(buf.data(), (size_t)k); off += (uint64_t)k;
-                    }
-                    if (fd >= 0) close(fd);
-                    finish_out(inst);
-                });
-            }
-        };
-
-        if (nslices) start_fill(0);
-        for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
-            pool.wait(fill_group[s & 1]);
-            rc = launch_gpu(s);
-            if (rc) break;
-            if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
-            if (s + 1 < nslices) start_fill(s + 1);
-            if (s >= 1) write_slice(s - 1);
-        }
-        if (rc == ZWZ_OK && nslices) {
-            hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
-            if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_slice(nslices - 1);
-        }
-        pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(md5_group);
-        (void)hipStreamSynchronize(c->stream);
-        free_slices(sl);
-        // instances that never received a decodable record still get created (the reference opens on
-        // the first record of a path)
-        for (uint32_t i = 0; i < insts.size(); i++)
-            if (insts[i].order.empty()) { open_out(i); finish_out(i); }
+        if (!parse_shard(blob, insts)) { damaged = true; if (rank == 0 || !split) fprintf(stderr, "Malformed shard (damaged from some record on): %s\n", shards[j].c_str()); }
+        DecodeSink sink{dst_dir, insts, mismatches, log_mutex};
+        rc = split ? decode_shard_split(c, pool, blob, insts, sink, rank, nranks, exchange, user) : decode_whole_shard(c, pool, blob, insts, sink);
         if (rc) break;
     }
     if (md5_mismatches) *md5_mismatches = mismatches.load();
+    { std::string why; if (pool.failed(&why) && rc == ZWZ_OK) { set_error("a pipeline task failed: %s", why.c_str()); rc = ZWZ_E_IO; } }
+    if (rc == ZWZ_OK && damaged) { set_error("a shard in %s ends inside a record; what precedes the damage was decoded", src_dir); rc = ZWZ_E_FORMAT; }
     return rc;
 }
 
-}  // extern "C"
+}  // namespace

@@ -7,7 +7,7 @@ Sources of truth:
     Python's zlib module -- payload = zlib.compress(chunk, 6)[:65535]   (compression.cpp:119-132)
   * shards / decompressed trees / file ordering: the reference binary itself, run here as
     1, 2 and 3 MPI ranks (README.md:59) on the tree from tests/corpus.golden_tree().
-Outputs: chunks.json, micro.json, tree.json, tree_N1/compressed_0.zwz
+Outputs: chunks.json, micro.json, tree.json, tree_N1/compressed_0.zwz, edges.json
 """
 import hashlib, json, os, shutil, subprocess, sys, tempfile, zlib
 
@@ -99,10 +99,40 @@ def mint_tree():
     return out
 
 
+def mint_edges():
+    """What the REFERENCE's decoder makes of damaged / reordered variants of the golden shard (tests/zwz_records.py derives
+    them, byte for byte reproducibly): decoded files and the number of "MD5 mismatch" lines."""
+    import zwz_records
+    good = open(os.path.join(HERE, "tree_N1", "compressed_0.zwz"), "rb").read()
+    out = {}
+    for name, blob in zwz_records.edge_shards(good).items():
+        work = tempfile.mkdtemp(prefix="zwz_edge_")
+        try:
+            os.makedirs(os.path.join(work, "in"))
+            with open(os.path.join(work, "in", "compressed_0.zwz"), "wb") as f:
+                f.write(blob)
+            r = subprocess.run([REF_MAIN, "decompress", os.path.join(work, "in"), os.path.join(work, "out")],
+                               capture_output=True, text=True, timeout=120)
+            decoded = {}
+            for root, _, names in os.walk(os.path.join(work, "out")):
+                for n in names:
+                    p = os.path.join(root, n)
+                    rel = os.path.relpath(p, os.path.join(work, "out"))
+                    if all(32 <= ord(ch) < 127 for ch in rel):     # (a cut header makes the reference try a garbage path)
+                        b = open(p, "rb").read()
+                        decoded[rel] = {"size": len(b), "sha256": sha(b)}
+            out[name] = {"shard_size": len(blob), "shard_sha256": sha(blob), "exit": r.returncode, "decoded": decoded,
+                         "md5_mismatches": r.stderr.count("MD5 mismatch for file:")}
+        finally:
+            shutil.rmtree(work)
+    return out
+
+
 if __name__ == "__main__":
     assert zlib.ZLIB_RUNTIME_VERSION == "1.2.11", zlib.ZLIB_RUNTIME_VERSION
     assert os.path.exists(REF_MAIN), "build oracle/_ref/main first: make -C oracle ref"
     json.dump(mint_micro(), open(os.path.join(HERE, "micro.json"), "w"), indent=0)
     json.dump(mint_chunks(), open(os.path.join(HERE, "chunks.json"), "w"), indent=0)
     json.dump(mint_tree(), open(os.path.join(HERE, "tree.json"), "w"), indent=1)
+    json.dump(mint_edges(), open(os.path.join(HERE, "edges.json"), "w"), indent=1)
     print("golden fixtures written")

@@ -38,7 +38,7 @@ def _worker(rank, world, init_file, src, dst, record, gather, result_dir):
 
     os.environ["ZWZ_FILE_RECORD"] = record if rank == 0 else "/nonexistent"   # only rank 0 may touch the list
     out = io.StringIO()
-    rc = cli.run("compress", src, dst, compress_fn=compress_fn, decompress_fn=lambda a, b: 0,
+    rc = cli.run("compress", src, dst, compress_fn=compress_fn, decompress_fn=lambda a, b, r, n, ag: 0,
                  sort_fn=lambda p: record, count_fn=count_fn, gather=gather, out=out)
     # helpers round-trip too
     payload = cli.broadcast_bytes(b"list-from-rank-0" * 1000 if rank == 0 else b"", 0)
@@ -97,7 +97,7 @@ def _idle_worker(rank, world, init_file, src, dst, record, result_dir):
     os.environ["ZWZ_FILE_RECORD"] = record
     out = io.StringIO()
     cli.run("compress", src, dst, compress_fn=lambda a, b, c, r, n: oracle.compress_shard(a, b, c, r, n),
-            decompress_fn=lambda a, b: 0, sort_fn=lambda p: record,
+            decompress_fn=lambda a, b, r, n, ag: 0, sort_fn=lambda p: record,
             count_fn=lambda path: sum(1 for line in open(path).read().split("\n") if line.strip()), out=out)
     open(os.path.join(result_dir, "r%d.txt" % rank), "w").write(out.getvalue())
     dist.destroy_process_group()
@@ -116,3 +116,102 @@ def test_more_ranks_than_files_leaves_idle_ranks_without_shard(tmp_path):
     mp.spawn(_idle_worker, args=(2, str(tmp_path / "rdzv"), str(src), str(tmp_path / "dst"), str(rec), str(res)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path / "dst")) == ["compressed_0.zwz"]
     assert "No file to compress" in open(res / "r1.txt").read()
+
+
+def _split_decode_standin(oracle, src_dir, dst_dir, rank, world, allgather):
+    """The protocol of zwz_decompress_dir_ranked (include/zwz.h) with the oracle as the decoder: whole shards round-robin when
+    there is one per rank, else contiguous record ranges + an all-gather of decoded byte counts.  Exercises the launcher's
+    side of the contract (who is called, what the exchange carries) without a GPU."""
+    import zwz_records
+    shards = sorted(n for n in os.listdir(src_dir) if n.endswith(".zwz"))
+    if len(shards) >= world:
+        bad = 0
+        for j, n in enumerate(shards):
+            if j % world == rank:
+                bad += oracle.decompress_shard(os.path.join(src_dir, n), dst_dir)
+        return bad
+    for n in shards:
+        recs = zwz_records.parse(open(os.path.join(src_dir, n), "rb").read())      # reference-written: already in decode order
+        T = len(recs)
+        j0, j1 = T * rank // world, T * (rank + 1) // world
+        mine = [(r[0], oracle.inflate(r[3])[0]) for r in recs[j0:j1]]
+        first, last = (mine[0][0], mine[-1][0]) if mine else (None, None)
+        ids = {p: i for i, p in enumerate(dict.fromkeys(r[0] for r in recs))}
+        vals = [ids[first] if mine else (1 << 64) - 1, sum(len(b) for p, b in mine if p == first),
+                ids[last] if mine else (1 << 64) - 1, sum(len(b) for p, b in mine if p == last), 0]
+        allv = allgather(vals)
+        assert len(allv) == 5 * world
+        cursor = {}
+        if mine:
+            cursor[first] = sum(allv[5 * r + 3] for r in range(rank) if allv[5 * r + 2] == ids[first])
+            for g, (path, data) in enumerate(mine):
+                full = os.path.join(dst_dir, path.decode())
+                begins = j0 + g == 0 or recs[j0 + g - 1][0] != path
+                if begins:
+                    os.makedirs(os.path.dirname(full), exist_ok=True)
+                    open(full, "wb").close()
+        allgather([0])                                   # files exist before anyone joins one further in
+        for path, data in mine:
+            full = os.path.join(dst_dir, path.decode())
+            fd = os.open(full, os.O_WRONLY)
+            os.pwrite(fd, data, cursor.get(path, 0))
+            os.close(fd)
+            cursor[path] = cursor.get(path, 0) + len(data)
+        allgather([0])                                   # barrier before verification
+    return 0
+
+
+def _decompress_worker(rank, world, init_file, src, dst, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_binding
+    cli = importlib.import_module(PKG + ".cli")
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    oracle = oracle_binding.load()
+    calls = []
+
+    def decompress_fn(a, b, r, n, allgather):
+        calls.append((r, n, allgather is not None))
+        return _split_decode_standin(oracle, a, b, r, n, allgather)
+
+    out = io.StringIO()
+    rc = cli.run("decompress", src, dst, compress_fn=lambda *a: 0, decompress_fn=decompress_fn, sort_fn=lambda p: "", count_fn=lambda p: 0, out=out)
+    big = cli.allgather_u64([rank, (1 << 64) - 1 - rank])
+    with open(os.path.join(result_dir, "r%d.json" % rank), "w") as f:
+        json.dump({"rc": rc, "calls": calls, "stdout": out.getvalue(), "big": big}, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nshards", [(2, 1), (3, 1), (2, 2)])
+def test_multirank_decompress_matches_reference_tree(tmp_path, golden_dir, world, nshards):
+    """Decompression shared by N ranks: one shard split by record ranges (BASELINE config 5's shape), and a
+    shard per rank.  The decoded tree must be the reference's own (lossy) tree."""
+    import shutil
+    import torch.multiprocessing as mp
+    import oracle_binding
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"][str(nshards)]
+    src = tmp_path / "zwz"
+    src.mkdir()
+    if nshards == 1:
+        shutil.copy(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), src / "compressed_0.zwz")
+    else:
+        tree = tmp_path / "tree"
+        _write_tree(str(tree))
+        rec = tmp_path / "list.txt"
+        rec.write_text(run["sorted_list"])
+        o = oracle_binding.load()
+        for r in range(nshards):
+            assert o.compress_shard(str(tree), str(src), str(rec), r, nshards) == 0
+    dst = tmp_path / "back"
+    res = tmp_path / "res"
+    res.mkdir()
+    mp.spawn(_decompress_worker, args=(world, str(tmp_path / "rdzv"), str(src), str(dst), str(res)), nprocs=world, join=True)
+    for rel, want in run["decoded"].items():
+        b = open(dst / rel, "rb").read()
+        assert {"size": len(b), "sha256": sha(b)} == want, rel
+    for r in range(world):
+        info = json.load(open(res / ("r%d.json" % r)))
+        assert info["rc"] == 0 and info["calls"] == [[r, world, True]]
+        assert info["big"] == [v for k in range(world) for v in (k, (1 << 64) - 1 - k)]
+        assert ("Time Taken:" in info["stdout"]) == (r == 0)

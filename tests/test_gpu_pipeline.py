@@ -1,0 +1,322 @@
+"""GPU parity tests, second file: the configurations and corners round 1 left without byte-level evidence -- the bench's
+own workspace size, a mixed-content soak, reordered / damaged shards, decompression shared by several ranks, stale
+rendezvous markers, the opt-in loss-free chunk size.  All through the C ABI; bit-exact."""
+import hashlib
+import importlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+CHUNK, STRIDE = 65535, 65536
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def zwz():
+    return importlib.import_module("parallel-data-compression-and-decompression_amd")
+
+
+@pytest.fixture(scope="module")
+def codec(zwz):
+    c = zwz.Codec(0, 1024)
+    yield c
+    c.close()
+
+
+def _cli():
+    return os.path.join(ROOT, "parallel-data-compression-and-decompression_amd", "main")
+
+
+def _tree_of(root):
+    out = {}
+    for d, _, names in os.walk(root):
+        for n in names:
+            b = open(os.path.join(d, n), "rb").read()
+            out[os.path.relpath(os.path.join(d, n), root)] = {"size": len(b), "sha256": sha(b)}
+    return out
+
+
+def _write_tree(root):
+    files = corpus.golden_tree()
+    for rel, data in files.items():
+        p = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "wb") as f:
+            f.write(data)
+    return files
+
+
+# ---------------------------------------------------------------------------------------------- bench-sized batches
+@pytest.mark.parametrize("workload", ["random", "text"])
+def test_full_batch_at_bench_workspace_is_bit_identical(zwz, oracle, workload):
+    """BASELINE configs[1] / [2] at full size (10 000 x 256 KiB = 50 000 chunks) the way bench.py runs them -- ONE launch
+    per kernel over a 51 200-chunk workspace -- against the same chunks run in 1 024-chunk slices (the size every other
+    parity test uses), byte for byte, plus an oracle sample and the device-side round-trip comparison."""
+    torch = pytest.importorskip("torch")
+    import bench
+    import workloads
+    dev = torch.device("cuda", 0)
+    d_in, d_off, d_len, n, raw, host_file = workloads.build_equal_files(torch, dev, workload, 10000, 262144)
+    assert n == 50000
+    outs = []
+    for max_batch in (51200, 1024):
+        c = zwz.Codec(0, max_batch)
+        try:
+            d_out = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
+            d_olen = torch.zeros(n, dtype=torch.int32, device=dev)
+            c.deflate_dev(d_in, d_off, d_len, d_out, d_olen)
+            c.sync()
+            if max_batch == 51200:
+                d_back = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
+                d_blen = torch.zeros(n, dtype=torch.int32, device=dev)
+                d_stat = torch.zeros(n, dtype=torch.int32, device=dev)
+                c.inflate_dev(d_out, d_off, d_olen, d_back, d_blen, d_stat)
+                c.sync()
+                v = bench.verify_bytes(torch, d_in, d_len, d_olen, d_back, d_blen, d_stat)
+                assert v["length_rule_ok"] and v["chunks_with_wrong_bytes"] == 0, v
+                assert v["truncated_chunks"] == (40000 if workload == "random" else 0)
+                o = bench.verify_oracle_sample(torch, 256, d_in, d_len, d_out, d_olen, d_back, d_blen)
+                assert o["sampled"] >= 250 and o["payload_mismatches"] == 0 and o["decode_mismatches"] == 0, o
+                del d_back
+            outs.append((d_out, d_olen))
+        finally:
+            c.close()
+    (a, alen), (b, blen) = outs
+    assert torch.equal(alen, blen)
+    col = torch.arange(STRIDE, device=dev, dtype=torch.int32).view(1, -1)
+    av, bv = a.view(n, STRIDE), b.view(n, STRIDE)
+    for c0 in range(0, n, 2048):
+        live = col < alen[c0:c0 + 2048].view(-1, 1)
+        assert not bool(((av[c0:c0 + 2048] != bv[c0:c0 + 2048]) & live).any().item()), c0
+
+
+def test_soak_mixed_chunks(codec, oracle):
+    """5 000 chunks of mixed kinds, sizes and stitched segments against the oracle, then corrupted / cut streams: lz_links'
+    single-exchange insert stands on a lane order the ISA manual does not spell out, so the evidence is
+    volume, every run."""
+    N, seed = 5000, 11
+    rs = corpus.splitmix64(seed, 6 * N)
+    kinds = [k for k in corpus.KINDS if k != "lz"]
+    chunks = []
+    for i in range(N):
+        r = int(rs[6 * i] % 100)
+        if r < 60:
+            kind = kinds[int(rs[6 * i + 1] % len(kinds))]
+            n = int(rs[6 * i + 2] % 65536) if r < 45 else 65535 - int(rs[6 * i + 2] % 700)
+            chunks.append(corpus.make(kind, seed * 100000 + i, n))
+        else:
+            parts, total = [], 0
+            for j in range(2 + int(rs[6 * i + 1] % 4)):
+                kind = kinds[int((rs[6 * i + 3] >> (7 * j)) % len(kinds))]
+                n = 200 + int((rs[6 * i + 4] >> (11 * j)) % 30000)
+                n = min(n, 65535 - total)
+                if n <= 0:
+                    break
+                parts.append(corpus.make(kind, seed * 100000 + 7 * i + j, n)); total += n
+            chunks.append(b"".join(parts))
+    got = codec.deflate_chunks(chunks)
+    back, _ = codec.inflate_chunks(got)
+    bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
+    assert not bad, bad[:10]
+    wrong = [i for i, (g, b) in enumerate(zip(got, back)) if b != oracle.inflate(g, 70000)[0]]
+    assert not wrong, wrong[:10]
+    import zlib
+    rs2 = corpus.splitmix64(seed + 77, 4 * 1500)
+    damaged = []
+    for i in range(1500):
+        z = bytearray(got[i]) if len(got[i]) > 8 else bytearray(zlib.compress(b"abcabcabc" * 50, 6))
+        mode = int(rs2[4 * i] % 4)
+        if mode == 0:
+            z[2 + int(rs2[4 * i + 1] % (len(z) - 2))] ^= 1 << int(rs2[4 * i + 2] % 8)
+        elif mode == 1:
+            z = z[:2 + int(rs2[4 * i + 1] % (len(z) - 2))]
+        elif mode == 2:
+            for j in range(3):
+                z[2 + int((rs2[4 * i + 1] >> (11 * j)) % (len(z) - 2))] ^= 0xff
+        else:
+            z += bytes(min(int(rs2[4 * i + 1] % 7), 65535 - len(z)))
+        damaged.append(bytes(z))
+    gb, _ = codec.inflate_chunks(damaged)
+    off = []
+    for i, (pl, g) in enumerate(zip(damaged, gb)):
+        w, total, st = oracle.inflate(pl, 1 << 20)
+        if total <= 65535 and g != w:
+            off.append(i)
+    assert not off, off[:10]
+
+
+# ---------------------------------------------------------------------------------------------- container corners
+def test_decompress_edge_shards_like_reference(zwz, codec, golden_dir, tmp_path):
+    """Reordered and damaged shards through the GPU path against what the reference binary made of them (edges.json):
+    records permuted within files (decompression.cpp:119-153), shards cut at a record boundary / inside an MD5 / inside a
+    payload / inside a header, an empty shard.  A damaged shard decodes up to the damage like the reference and then
+    reports ZWZ_E_FORMAT (the reference exits 0)."""
+    import zwz_records
+    edges = json.load(open(os.path.join(golden_dir, "edges.json")))
+    good = open(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), "rb").read()
+    for name, blob in zwz_records.edge_shards(good).items():
+        want = edges[name]
+        assert sha(blob) == want["shard_sha256"]
+        src, out = tmp_path / (name + "_in"), tmp_path / (name + "_out")
+        src.mkdir(); out.mkdir()
+        (src / "compressed_0.zwz").write_bytes(blob)
+        if name in ("cut_md5", "cut_payload", "cut_header"):
+            with pytest.raises(zwz.ZwzError) as ei:
+                codec.do_decompression(str(src), str(out))
+            assert ei.value.status == zwz.E_FORMAT, name
+            bad = ei.value.md5_mismatches
+        else:
+            bad = codec.do_decompression(str(src), str(out))
+        assert bad == want["md5_mismatches"], name
+        assert _tree_of(str(out)) == want["decoded"], name
+
+
+@pytest.mark.parametrize("nranks,nshards", [(2, 1), (3, 1), (2, 2), (2, 3)])
+def test_cli_multirank_decompress_matches_reference_tree(golden_dir, tmp_path, nranks, nshards):
+    """`main decompress` as N ranks on this box's GPU: ONE shard split into N record ranges (BASELINE
+    configs[4]'s shape) with the decoded byte counts all-gathered, and whole shards round-robin.  The tree must be the
+    reference's own (lossy) decoded tree; the MD5 mismatches it prints must be reported by some rank."""
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"][str(nshards)]
+    zdir = tmp_path / "zwz"
+    zdir.mkdir()
+    if nshards == 1:
+        shutil.copy(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), zdir / "compressed_0.zwz")
+    else:
+        import oracle_binding
+        src = tmp_path / "src"
+        _write_tree(str(src))
+        rec = tmp_path / "list.txt"
+        rec.write_text(run["sorted_list"])
+        o = oracle_binding.load()
+        for r in range(nshards):
+            assert o.compress_shard(str(src), str(zdir), str(rec), r, nshards) == 0
+    back = tmp_path / "back"
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS=str(nranks), ZWZ_DEVICE="0", ZWZ_RENDEZVOUS_TIMEOUT="120")
+        procs.append(subprocess.Popen([_cli(), "decompress", str(zdir), str(back)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "Operation: decompress" in outs[0][0] and "Processor Count: %d" % nranks in outs[0][0]
+    assert sum(o[1].count("MD5 mismatch for file:") for o in outs) == run["md5_mismatches"]
+    for rel, want in run["decoded"].items():
+        b = open(back / rel, "rb").read()
+        assert {"size": len(b), "sha256": sha(b)} == want, rel
+    assert not [n for n in os.listdir(back) if n.startswith(".zwz_")]          # rendezvous markers cleaned up
+
+
+def test_cli_ignores_stale_markers_of_a_crashed_run(golden_dir, tmp_path):
+    """A run that died leaves its rendezvous files in <dst>.  The next run -- even under the SAME run id -- must not take
+    the dead run's list path, nor its completion markers, for its own (csrc/main.cpp: nonce handshake)."""
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["2"]
+    src = tmp_path / "data" / "src"
+    _write_tree(str(src))
+    rec = tmp_path / "list.txt"
+    rec.write_text(run["sorted_list"])
+    wrong = tmp_path / "stale_list.txt"
+    wrong.write_text("hello.txt\n")                                        # what a stale publication would point at
+    dst = tmp_path / "zwz"
+    dst.mkdir()
+    stem = ".zwz_compress_FIXEDRUN"
+    (dst / (stem + "_list_999s1")).write_text("999s1\n%s\n888s1\n" % wrong)   # dead rank 0's publication naming dead rank 1
+    (dst / (stem + "_here_1_888s1")).write_text("888s1\n")
+    (dst / (stem + "_done_1_999s1")).write_text("0\n")
+    (dst / ".zwz_compress_list_ready").write_text("")                         # round-1 style markers
+    (dst / ".zwz_compress_list").write_text(str(wrong))
+    procs = []
+    for r in (1, 0):                                                          # rank 1 first: it must wait for the live rank 0
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS="2", ZWZ_DEVICE="0", ZWZ_RUN_ID="FIXEDRUN", ZWZ_RENDEZVOUS_TIMEOUT="120")
+        if r == 0:
+            env["ZWZ_FILE_RECORD"] = str(rec)
+        procs.append(subprocess.Popen([_cli(), "compress", str(src), str(dst)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = {n: open(dst / n, "rb").read() for n in sorted(os.listdir(dst)) if n.endswith(".zwz")}
+    assert {n: {"size": len(b), "sha256": sha(b)} for n, b in got.items()} == run["shards"]
+    assert not [n for n in os.listdir(dst) if n.startswith(stem)]             # this run id's files are gone, stale ones included
+
+
+def test_cli_reports_a_failed_rank(tmp_path):
+    """Rank 0 must not report success when another rank failed (round 1: return codes of other ranks were ignored)."""
+    src = tmp_path / "data" / "src"
+    _write_tree(str(src))
+    dst = tmp_path / "zwz"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS="2", ZWZ_DEVICE="0" if r == 0 else "4711", ZWZ_RENDEZVOUS_TIMEOUT="60")
+        if r == 1:
+            env["HIP_VISIBLE_DEVICES"] = "-1"                                # rank 1 finds no GPU: zwz_ctx_create fails
+        procs.append(subprocess.Popen([_cli(), "compress", str(src), str(dst)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert procs[1].returncode != 0, outs[1]
+    assert procs[0].returncode != 0 and "rank 1 failed" in outs[0][1], outs[0]
+
+
+# ---------------------------------------------------------------------------------------------- opt-in loss-free mode
+def test_lossless_chunk_size_roundtrips_incompressible_files(zwz, oracle, tmp_path):
+    """SURVEY.md section 8 f4, opt-in: with 65 504-byte chunks no level-6 stream exceeds the reference's 65 535-byte payload buffer
+    (compression.cpp:127-132), so incompressible files come back whole with a matching MD5 -- from this decoder AND from
+    the reference's own, which reads the unchanged container.  The default stays bit-exact (every other test)."""
+    src = tmp_path / "data" / "src"
+    src.mkdir(parents=True)
+    files = {"r1.bin": corpus.random_bytes(71, 262144), "r2.bin": corpus.random_bytes(72, 65504), "r3.bin": corpus.random_bytes(73, 65535),
+             "r4.bin": corpus.random_bytes(74, 2 * 65504), "t.txt": corpus.text_like(75, 150000), "e.bin": b""}
+    for n, d in files.items():
+        (src / n).write_bytes(d)
+    rec = tmp_path / "list.txt"
+    rec.write_text("".join(n + "\n" for n in files))
+    c = zwz.Codec(0, 256)
+    try:
+        lossy, loss_free = tmp_path / "lossy", tmp_path / "lossfree"
+        lossy.mkdir(); loss_free.mkdir()
+        c.do_compression(str(src), str(lossy), str(rec), 0, 1)
+        c.set_chunk_size(zwz.LOSSLESS_CHUNK_SIZE)
+        c.do_compression(str(src), str(loss_free), str(rec), 0, 1)
+        c.set_chunk_size(0)
+        b1, b2 = tmp_path / "b1", tmp_path / "b2"
+        b1.mkdir(); b2.mkdir()
+        assert c.do_decompression(str(lossy), str(b1)) == 4                   # the reference's behaviour: four random files come back short
+        assert c.do_decompression(str(loss_free), str(b2)) == 0
+        for n, d in files.items():
+            assert open(b2 / n, "rb").read() == d, n
+        import zwz_records
+        recs = zwz_records.parse(open(loss_free / "compressed_0.zwz", "rb").read())
+        assert max(len(r[3]) for r in recs) == 65535 and [r[1] for r in recs if r[0] == b"r4.bin"] == [0, 1, 2]   # 65504 + 65504 + empty
+        for r in recs:                                                        # every payload is the oracle's stream of its 65 504-byte chunk
+            data = files[r[0].decode()]
+            assert r[3] == oracle.payload(data[r[1] * 65504:(r[1] + 1) * 65504])
+    finally:
+        c.close()
+    ref = os.path.join(ROOT, "oracle", "_ref", "main")
+    if os.path.exists(ref):                                                   # the reference's own decoder reads the loss-free shard
+        b3 = tmp_path / "b3"
+        r = subprocess.run([ref, "decompress", str(loss_free), str(b3)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "MD5 mismatch" not in r.stderr
+        for n, d in files.items():
+            assert open(b3 / n, "rb").read() == d, n
+
+
+def test_lossless_env_switch_through_the_cli(tmp_path):
+    src = tmp_path / "data" / "src"
+    src.mkdir(parents=True)
+    data = corpus.random_bytes(81, 200000)
+    (src / "r.bin").write_bytes(data)
+    dst, back = tmp_path / "zwz", tmp_path / "back"
+    env = dict(os.environ, ZWZ_LOSSLESS="1")
+    r = subprocess.run([_cli(), "compress", str(src), str(dst)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([_cli(), "decompress", str(dst), str(back)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "MD5 mismatch" not in r.stderr
+    assert open(back / "r.bin", "rb").read() == data

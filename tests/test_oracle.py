@@ -135,3 +135,33 @@ def test_window_slide_corner(oracle):
         a = bytearray(corpus.random_bytes(777 + t, n))
         a[65274:65274 + 6] = a[32768:32768 + 6]
         assert oracle.deflate6(bytes(a)) == zlib.compress(bytes(a), 6)
+
+
+def _tree_of(root):
+    out = {}
+    for d, _, names in os.walk(root):
+        for n in names:
+            b = open(os.path.join(d, n), "rb").read()
+            out[os.path.relpath(os.path.join(d, n), root)] = {"size": len(b), "sha256": sha(b)}
+    return out
+
+
+def test_edge_shards_match_reference(oracle, golden_dir, tmp_path):
+    """Reordered and damaged shards (tests/zwz_records.py) against what the reference binary itself made of them
+    (edges.json, minted by make_golden.py): records out of order incl. a last chunk that arrives early, a shard cut at a
+    record boundary, inside an MD5, inside a payload, inside a header, and an empty shard (decompression.cpp:65-162)."""
+    import zwz_records
+    edges = json.load(open(os.path.join(golden_dir, "edges.json")))
+    good = open(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), "rb").read()
+    shards = zwz_records.edge_shards(good)
+    assert set(shards) == set(edges)
+    for name, blob in shards.items():
+        want = edges[name]
+        assert (len(blob), sha(blob)) == (want["shard_size"], want["shard_sha256"]), "edge derivation drifted: " + name
+        out = tmp_path / name
+        out.mkdir()
+        shard = tmp_path / (name + ".zwz")
+        shard.write_bytes(blob)
+        bad = oracle.decompress_shard(str(shard), str(out))
+        assert bad == want["md5_mismatches"], name
+        assert _tree_of(str(out)) == want["decoded"], name
