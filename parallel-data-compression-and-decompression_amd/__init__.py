@@ -176,6 +176,9 @@ class Codec:
                                        d_digests.data_ptr()), "zwz_md5_files_dev")
 
     # ---- device-resident torch tensors (asynchronous on self.stream) ---------------------------
+    # self.stream is the context's own non-blocking HIP stream, NOT torch's current stream: work torch has queued on the
+    # tensors (a torch.zeros fill, a copy) must be complete before these calls -- torch.cuda.synchronize(), or an event --
+    # and self.sync() must precede any torch read of the results.
     def deflate_dev(self, d_in, d_off, d_len, d_out, d_out_len, out_stride=DEV_STRIDE):
         n = d_len.numel()
         _check(lib().zwz_deflate_batch_dev(self._h, d_in.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n, d_out.data_ptr(),

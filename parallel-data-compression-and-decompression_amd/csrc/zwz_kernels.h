@@ -24,7 +24,7 @@ constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
 constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + kMaskWords * 8 + kMaskWords * 2 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 80496: two workgroups per CU
-constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
+constexpr uint32_t kInflateThreads = 64;                        // one chunk (one wave, ~12 KB of LDS) per workgroup: 13 per CU
 constexpr int kNumDeflateStages = 6;
 
 struct ChunkInfo { uint32_t n_sym, n_blocks; };

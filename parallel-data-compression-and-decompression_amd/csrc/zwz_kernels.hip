@@ -1676,24 +1676,105 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// inflate: one wave per chunk.  Lane 0 owns block headers and table construction; symbols are decoded by the
-// whole wave from a window of the bit stream (see the Huffman branch below) and the wave moves the bytes.
-// The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane,
-// coalesced): a round consumes < 1 KiB, so topping the ring up to pos + 1 KiB before every round keeps the
-// decoders off global memory entirely.
+// inflate: one wave per chunk.  Lane 0 owns block headers and table construction; the symbols of a Huffman block are
+// decoded by the whole wave, a ROUND at a time, and the wave moves the bytes.
+//
+// Decoding is sequential only in where symbols START.  A round looks at the next 64 x kSubBits bits of the stream, one
+// subsequence per lane (self-synchronising parallel Huffman decoding):
+//   1. sync   every lane decodes symbol after symbol from its start until it crosses into the next lane's
+//             subsequence, and hands the bit position it ends at to that lane as its corrected start.  Lane 0's start
+//             is exact; a lane that started inside a symbol usually falls into step with the true sequence within a few
+//             symbols, so its END is right long before its start is.  Repeated until no start changes (2-4 times on
+//             text; never more than 64: after k passes lanes 0..k-1 are final).
+//   2. emit   symbol and byte counts per lane -> exclusive prefix sums -> every symbol's index and output position; one
+//             more pass with values writes (value, position) per symbol and marks each symbol's first output byte.
+//             Whatever ends the round is found here, in stream order: end of block, an invalid or incomplete code, a
+//             distance beyond the output, the 65535-byte cap, or simply the round's capacity.
+//   3. copy   byte-parallel: a max-scan over the marks names the symbol that owns each output byte; back-references into
+//             the round itself are chased through LDS; everything older is in global memory, every store of an earlier
+//             round drained.  64 bytes per trip, coalesced stores.
+// The round-1 kernel decoded at EVERY bit offset of a 256-bit window (one real symbol per ~9 speculative decodes, ~38
+// wave instructions per symbol, a 6-step owner search per output byte); a lane now decodes a handful of symbols in a row.
+// Codes longer than the fast tables are walked canonically by the lane that meets one (no sequential fallback), with
+// zlib's exact stopping behaviour: a symbol counts only if all of its bits are there, an error keeps what precedes it.
+// The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane, coalesced).
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
-constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
+constexpr uint32_t kSubBits = 32;          // bits of the stream per lane per round
+constexpr uint32_t kRoundSyms = 288;       // symbols a round can hold ...
+constexpr uint32_t kRoundBytes = 2048;     // ... and output bytes (a multiple of 64)
+static_assert(64 * kSubBits / 8 + 64 < kInfFill, "a round's window must fit what top_up keeps resident");
 
 struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
-    uint32_t batch[kBatch], pos[kBatch];
-    uint16_t jump[64 * kWinSlots + 8];       // window offset -> offset of the symbol after the one starting there (pointer doubling)
-    uint32_t flag[64 * kWinSlots / 4];       // one byte per window offset: reached from offset 0
+    uint2 sym[kRoundSyms];                                      // (literal byte | len << 16 | dist, output position)
+    __attribute__((aligned(16))) uint16_t own[kRoundBytes];     // per output byte of the round: 1 + index of the symbol that starts here, then of the one that owns it
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
-__global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+enum : uint32_t { kSyLit = 0, kSyMatch = 1, kSyEob = 2, kSyNeed = 3, kSyData = 4, kSyOverflow = 5, kSyCut = 6, kSyNone = 7 };
+
+// Canonical walk for a code the fast table does not hold (inflate_core.h decode_symbol's slow path): 0 ok, kSyNeed, kSyData.
+static __device__ __forceinline__ uint32_t walk_code(const uint16_t* count, const uint16_t* sorted, uint64_t bits, int32_t avail,
+                                                     uint32_t& sym, uint32_t& len_out) {
+    int code = 0, first = 0, index = 0;
+    for (uint32_t len = 1; len <= 15; len++) {
+        if ((int32_t)len > avail) return kSyNeed;
+        code |= (int)((bits >> (len - 1)) & 1u);
+        const int c = count[len];
+        if (code - c < first) { sym = sorted[index + (code - first)]; len_out = len; return 0; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return kSyData;
+}
+
+// One symbol from a window of the stream (bit 0 = the symbol's first bit, >= 57 bits valid, `avail` of them payload).
+// Same decisions in the same order as inflate_decode_batch.
+static __device__ __forceinline__ uint32_t lane_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
+    nb = 0; val = 0;
+    if (avail <= 0) return kSyNeed;
+    const uint32_t e = t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
+    uint32_t l = e & 15u, s = e >> 4;
+    if (e == 0) { const uint32_t r = walk_code(t.lit_count, t.lit_sym, bits, avail, s, l); if (r) return r; }
+    else if ((int32_t)l > avail) return kSyNeed;
+    if (s < 256u) { nb = l; val = s; return kSyLit; }
+    if (s == 256u) { nb = l; return kSyEob; }
+    const uint32_t c = s - 257u;
+    if (c >= 29u) return kSyData;
+    const uint32_t xb = length_extra_bits(c);
+    if ((int32_t)(l + xb) > avail) return kSyNeed;
+    const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
+    const uint64_t rest = bits >> (l + xb);
+    const int32_t avail2 = avail - (int32_t)(l + xb);
+    const uint32_t de = t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+    uint32_t dl = de & 15u, d = de >> 4;
+    if (de == 0) { const uint32_t r = walk_code(t.dist_count, t.dist_sym, rest, avail2, d, dl); if (r) return r; }
+    else if ((int32_t)dl > avail2) return kSyNeed;
+    if (d >= 30u) return kSyData;
+    const uint32_t dxb = dist_extra_bits(d);
+    if ((int32_t)(dl + dxb) > avail2) return kSyNeed;
+    const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
+    nb = l + xb + dl + dxb; val = (len << 16) | dist;
+    return kSyMatch;
+}
+
+static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {          // as wave_scan_incl, with max (0 = identity)
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// byte `j` of a match that starts at output position p0 with distance d: where its value comes from
+static __device__ __forceinline__ uint32_t match_source(uint32_t j, uint32_t p0, uint32_t d) {
+    const uint32_t off = j - p0;
+    return off < d ? j - d : p0 - d + off % d;
+}
+
+__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                   const uint32_t* __restrict__ in_len, uint32_t n,
                                                                   uint8_t* __restrict__ out, uint64_t out_stride,
                                                                   uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
@@ -1721,13 +1802,18 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
+    auto window = [&](uint32_t a) -> uint64_t {        // the stream from bit a on: >= 57 bits
+        const uint32_t byte = (a >> 3) & (kInfRing - 1u);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
+        return (((uint64_t)hi << 32) | lo) >> (a & 7u);
+    };
 
     InflateState st;
     top_up(0);
     uint32_t go = 0;
     if (lane == 0) go = inflate_begin(st, m.ring, nin, kInfRing - 1u) ? 1u : 0u;
     go = __builtin_amdgcn_readfirstlane(go);
-    uint32_t fenced = 0;      // every output byte below this offset is visible to the whole wave
     while (go) {
         uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
         top_up(st.br.pos);
@@ -1764,220 +1850,126 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             }
             if (__builtin_amdgcn_readfirstlane(stop)) break;
         } else {
-            // Huffman block.  Decoding is sequential only in where symbols START; what a symbol is,
-            // given its start bit, is a pure table lookup.  So every lane decodes the symbol that would
-            // start at each of its kWinSlots bit offsets of a 256-bit window (window bit o <-> lane o & 63,
-            // slot o >> 6), and a short scalar loop then hops through the true chain with v_readlane,
-            // dropping the symbols into the batch registers with v_writelane.  (Lane 0 decoding alone
-            // cost ~1900 cycles per symbol.)  Codes longer than the fast tables, and anything odd, fall
-            // back to the sequential decoder for one symbol, which also keeps zlib's exact error and
-            // truncation behaviour.
-            enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
             uint32_t bp = 0, opos_u = 0;
             if (lane == 0) { bp = st.br.bit_pos(); opos_u = st.out_pos; }
             bp = __builtin_amdgcn_readfirstlane(bp); opos_u = __builtin_amdgcn_readfirstlane(opos_u);
             const uint32_t total_bits = nin * 8u;
             uint32_t block_done = 0, stop_status = kInfRunning;
+            constexpr uint32_t kDead = 0xffffffffu;                       // "the stream does not get here this round"
             while (!block_done) {
                 top_up(bp >> 3);
-                uint32_t inf[kWinSlots], val[kWinSlots];
-#pragma unroll
-                for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t a = bp + r * 64u + lane;
-                    const int32_t avail = (int32_t)total_bits - (int32_t)a;
-                    const uint32_t byte = (a >> 3) & (kInfRing - 1u);
-                    const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
-                    const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
-                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);      // >= 57 valid bits
-                    uint32_t kind = kSlow, nb = 0, v = 0;
-                    const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
-                    const uint32_t l = e & 15u, s = e >> 4;
-                    if (e != 0) {
-                        if (s < 256u) { kind = kLit; nb = l; v = s; }
-                        else if (s == 256u) { kind = kEob; nb = l; }
-                        else {
-                            const uint32_t c = s - 257u;
-                            kind = kErr;
-                            if (c < 29u) {
-                                const uint32_t xb = length_extra_bits(c);
-                                const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
-                                const uint64_t rest = bits >> (l + xb);
-                                const uint32_t de = m.t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
-                                const uint32_t dl = de & 15u, d = de >> 4;
-                                kind = kSlow;
-                                if (de != 0) {
-                                    kind = kErr;
-                                    if (d < 30u) {
-                                        const uint32_t dxb = dist_extra_bits(d);
-                                        const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
-                                        kind = kMatch; nb = l + xb + dl + dxb; v = (len << 16) | dist;
-                                    }
-                                }
+                // ---- 1. sync
+                const uint32_t bound = bp + kSubBits * (lane + 1u);
+                uint32_t start = bp + kSubBits * lane, endpos = 0, n_sym = 0, n_bytes = 0;
+                bool redo = true;
+                for (uint32_t pass = 0; pass < 64u; pass++) {
+                    if (redo) {
+                        uint32_t pos = start, ns = 0, nby = 0;
+                        bool stopped = start == kDead;
+                        for (;;) {
+                            const bool act = !stopped && pos < bound;
+                            if (__builtin_amdgcn_ballot_w64(redo && act) == 0) break;
+                            if (act) {
+                                uint32_t nb, val;
+                                const uint32_t k = lane_decode(m.t, window(pos), (int32_t)(total_bits - pos), nb, val);
+                                if (k <= kSyMatch) { ns++; nby += k == kSyLit ? 1u : val >> 16; pos += nb; }
+                                else stopped = true;
                             }
                         }
+                        endpos = stopped ? kDead : pos; n_sym = ns; n_bytes = nby;
                     }
-                    if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
-                    inf[r] = kind | (nb << 3); val[r] = v;
+                    uint32_t from_left = (uint32_t)__builtin_amdgcn_update_dpp((int)bp, (int)endpos, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps bp
+                    if (lane == 0) from_left = bp;
+                    redo = from_left != start;
+                    start = from_left;
+                    // Only the lanes up to the first one whose subsequence ends the round matter (an end of block, an
+                    // error, the payload's end): once THEIR starts agree with their left neighbours the sequence up to
+                    // that point is final, and what the lanes behind it hold is never looked at.  (Without this the "dead"
+                    // mark would walk to lane 63 one lane a pass at the end of every block.)
+                    const uint64_t enders = __builtin_amdgcn_ballot_w64(endpos == kDead);
+                    const uint64_t relevant = enders ? ((2ull << (uint32_t)__builtin_ctzll(enders)) - 1ull) : ~0ull;
+                    if ((__builtin_amdgcn_ballot_w64(redo) & relevant) == 0) {
+                        if (!((relevant >> lane) & 1ull)) { start = kDead; n_sym = 0; n_bytes = 0; }
+                        break;
+                    }
                 }
-                // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
-                // A scalar loop hopping through it with v_readlane took ~50 SALU instructions a symbol, and a CU has ONE
-                // scalar issue slot a cycle for its 20 waves: 70 % of this kernel's time on text.  So the orbit is marked
-                // by pointer doubling over the 256 offsets (<= 8 rounds, usually 5), ranks and output positions come from
-                // ballots and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols,
-                // end of block, an error, a code for the sequential decoder) -- the same decisions in the same order
-                // of precedence as the loop they replace.
-                constexpr uint32_t kSink = 64u * kWinSlots;
-                uint32_t jr[kWinSlots];
-                uint8_t* flag8 = reinterpret_cast<uint8_t*>(m.flag);
-                m.flag[lane] = lane == 0 ? 1u : 0u;                       // offset 0 is reached by definition
-#pragma unroll
-                for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t adv = r * 64u + lane + (inf[r] >> 3);
-                    jr[r] = (inf[r] & 7u) <= kMatch ? (adv < kSink ? adv : kSink) : kSink;      // only literals and matches lead on
-                    m.jump[r * 64u + lane] = (uint16_t)jr[r];
-                }
-                if (lane == 0) m.jump[kSink] = (uint16_t)kSink;
+                // ---- 2. emit
+                for (uint32_t i = lane; i < kRoundBytes / 8u; i += 64u) reinterpret_cast<uint4*>(m.own)[i] = make_uint4(0, 0, 0, 0);
+                const uint32_t sidx = wave_scan_incl(n_sym) - n_sym, ooff = wave_scan_incl(n_bytes) - n_bytes;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint64_t M[kWinSlots] = {1ull, 0ull, 0ull, 0ull};           // reached offsets, slot by slot (wave-uniform)
-                for (uint32_t round = 0; round < 8; round++) {
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++)                 // everything reached so far marks what lies 2^round symbols on
-                        if (((M[r] >> lane) & 1ull) && jr[r] < kSink) flag8[jr[r]] = 1;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    bool grown = false;
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) {
-                        const uint64_t now = __ballot(flag8[r * 64u + lane] != 0);
-                        grown = grown || now != M[r];
-                        M[r] = now;
-                    }
-                    if (!grown) break;
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) jr[r] = m.jump[jr[r]];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) m.jump[r * 64u + lane] = (uint16_t)jr[r];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                }
-                // Ranks (symbol index in the batch) and output positions of the reached offsets, in window order; the first
-                // reached offset at which the batch must end decides how the round ends.  Symbols go into the batch arrays
-                // as they are ranked; the entries from the end of the batch on are blanked afterwards.
-                m.pos[lane] = 0xffffffffu;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t base = 0, carry = 0, cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
-                bool ended = false;
-#pragma unroll
-                for (uint32_t r = 0; r < kWinSlots; r++) {
-                    // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow,
-                    // ~100 scalar instructions per slot -- and the scalar unit is what this kernel runs out of)
-                    const uint32_t kd = inf[r] & 7u;
-                    const uint32_t mk = (uint32_t)(M[r] >> lane) & 1u;
-                    const uint32_t rank = base + rank_in(M[r]);
-                    const uint32_t is_lit = (uint32_t)(kd == kLit), is_match = (uint32_t)(kd == kMatch), mlen = val[r] >> 16;
-                    const uint32_t ol = mk * (is_lit + is_match * mlen);
-                    const uint32_t sc = wave_scan_incl(ol);
-                    const uint32_t pos = opos_u + carry + sc - ol;
-                    const uint32_t ends = mk & ((uint32_t)(rank >= kBatch) | (uint32_t)(kd >= kEob) | (is_lit & (uint32_t)(pos >= kChunk)) |
-                                                (is_match & ((uint32_t)((val[r] & 0xffffu) > pos) | (uint32_t)(pos + mlen > kChunk))));
-                    if (mk & (ends ^ 1u)) { m.batch[rank] = val[r]; m.pos[rank] = pos; }      // not at an end implies rank < kBatch
-                    const uint64_t C = __ballot(ends != 0);
-                    if (!ended && C) {                                     // wave-uniform: the round ends at this offset
-                        ended = true;
-                        const uint32_t lc = (uint32_t)__builtin_ctzll(C);
-                        const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_rank = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)lc);
-                        const uint32_t c_val = (uint32_t)__builtin_amdgcn_readlane((int)val[r], (int)lc);
-                        opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
-                        cur = r * 64u + lc;
-                        k = c_rank < kBatch ? c_rank : kBatch;
-                        if (c_rank >= kBatch) { /* batch full: the next round starts at this symbol */ }
-                        else if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
-                        else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
-                        else if (c_kind == kEob) { cur += (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)lc); stop = kEob; }
-                        else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
-                    }
-                    if (!ended && M[r]) {                                  // so far plain symbols: the chain leaves the window behind the last of them
-                        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(M[r]);
-                        cur = r * 64u + ll + (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)ll);
-                    }
-                    base += (uint32_t)__popcll(M[r]);
-                    carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
-                }
-                if (!ended) { k = base; opos_new = opos_u + carry; }
-                bp += cur;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (lane >= k) m.pos[lane] = 0xffffffffu;                  // symbols ranked behind the end of the batch do not belong to it
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // The wave moves the bytes of this batch, one output byte per lane per trip: find the
-                // symbol that produces the byte (binary search over the batch's start offsets), follow
-                // back-references that point into this same batch until they land on a literal of the
-                // batch or on output of an earlier batch, then load/store.  All loads of a trip are in
-                // flight together (copying match by match cost one L2 round trip per match: ~9 ms a chunk).
-                // The batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
-                // owners here; indexed LDS reads are also cheaper than eight bpermutes).
-                const uint32_t bstart = opos_u;
-                const uint32_t bbytes = opos_new - bstart;
-                opos_u = opos_new;
-                auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
-                    uint32_t lo = 0;
-#pragma unroll
-                    for (uint32_t stp = 32; stp >= 1; stp >>= 1) { const uint32_t q = m.pos[(lo + stp) & 63u]; if (q <= pos) lo += stp; }
-                    ov = m.batch[lo]; op = m.pos[lo];
-                };
-                bool need_fence = false;
-                for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
-                    const uint32_t pos = bstart + j0 + lane;
-                    const bool in = j0 + lane < bbytes;
-                    uint32_t ov = 0, op = 0;
-                    owner(in ? pos : bstart, ov, op);
-                    uint32_t src = 0; bool lit = ov < 256u;
-                    if (!lit) { const uint32_t d = ov & 0xffffu; src = op - d + ((pos - op) % d); }
-                    // chase references into this batch (wave-uniform loop, lanes drop out as they resolve)
-                    while (__ballot(in && !lit && src >= bstart)) {
-                        const bool go2 = in && !lit && src >= bstart;
-                        uint32_t ov2 = 0, op2 = 0;
-                        owner(go2 ? src : bstart, ov2, op2);
-                        if (go2) {
-                            if (ov2 < 256u) { lit = true; ov = ov2; }
-                            else { const uint32_t d = ov2 & 0xffffu; src = op2 - d + ((src - op2) % d); }
-                        }
-                    }
-                    const uint64_t far = __ballot(in && !lit && src + 1u > fenced);
-                    if (far) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = bstart; }
-                    // back-references read bytes this CU stored a moment ago: agent-scope (sc1) loads are served
-                    // by L2 and cannot hit a stale L1 line that was cached before the store
-                    if (in) dst[pos] = lit ? (uint8_t)ov : __hip_atomic_load(&dst[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    (void)need_fence;
-                }
-                if (stop == kEob) block_done = 1;
-                else if (stop == kSlow) {
-                    // one symbol through the sequential decoder (long code, or its exact failure mode)
-                    uint32_t k1 = 0, d1 = 0, nbp = bp, nop = opos_u, stt = kInfRunning;
-                    if (lane == 0) {
-                        st.br.seek_bit(bp); st.out_pos = opos_u;
-                        bool d;
-                        k1 = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d, 1u);
-                        d1 = d; nbp = st.br.bit_pos(); nop = st.out_pos; stt = st.status;
-                    }
-                    k1 = __builtin_amdgcn_readfirstlane(k1); d1 = __builtin_amdgcn_readfirstlane(d1);
-                    bp = __builtin_amdgcn_readfirstlane(nbp); opos_u = __builtin_amdgcn_readfirstlane(nop);
-                    stt = __builtin_amdgcn_readfirstlane(stt);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (k1) {
-                        const uint32_t mv = m.batch[0], mp = m.pos[0];
-                        if (mv < 256u) { if (lane == 0) dst[mp] = (uint8_t)mv; }
-                        else {
-                            const uint32_t len = mv >> 16, dist = mv & 0xffffu;
-                            const uint32_t from = mp - dist, span = len < dist ? len : dist;
-                            if (from + span > fenced) {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                                __builtin_amdgcn_s_waitcnt(0);
-                                fenced = mp;
+                uint32_t e_kind = kSyNone, e_pos = start == kDead ? 0u : start, e_nb = 0, e_syms = 0, e_bytes = 0;
+                {
+                    bool stopped = start == kDead;
+                    for (;;) {
+                        const bool act = !stopped && e_pos < bound;
+                        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+                        if (act) {
+                            uint32_t nb, val;
+                            uint32_t k = lane_decode(m.t, window(e_pos), (int32_t)(total_bits - e_pos), nb, val);
+                            const uint32_t p = opos_u + ooff + e_bytes, si = sidx + e_syms;
+                            const uint32_t blen = k == kSyLit ? 1u : val >> 16;
+                            if (k <= kSyMatch) {
+                                if (k == kSyMatch && (val & 0xffffu) > p) k = kSyData;                 // too far back
+                                else if (p + blen > kChunk) k = kSyOverflow;
+                                else if (si >= kRoundSyms || p + blen - opos_u > kRoundBytes) k = kSyCut;   // the round is full: the next one starts here
                             }
-                            for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = __hip_atomic_load(&dst[from + (i % dist)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (k <= kSyMatch) {
+                                m.sym[si] = make_uint2(val, p);
+                                m.own[p - opos_u] = (uint16_t)(si + 1u);
+                                e_syms++; e_bytes += blen; e_pos += nb;
+                            } else { e_kind = k; e_nb = nb; stopped = true; }
                         }
                     }
-                    if (d1) { block_done = 1; stop_status = stt; }
-                } else if (stop != 0xffu) { block_done = 1; }          // need / error / overflow: status already set
+                }
+                // the round ends at the first lane, in stream order, that met something other than a plain symbol
+                const uint64_t enders = __builtin_amdgcn_ballot_w64(e_kind != kSyNone);
+                const uint32_t el = enders ? (uint32_t)__builtin_ctzll(enders) : 63u;
+                const uint32_t r_kind = enders ? (uint32_t)__builtin_amdgcn_readlane((int)e_kind, (int)el) : kSyNone;
+                const uint32_t r_pos = (uint32_t)__builtin_amdgcn_readlane((int)e_pos, (int)el);
+                const uint32_t r_nb = (uint32_t)__builtin_amdgcn_readlane((int)e_nb, (int)el);
+                const uint32_t nbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + e_bytes), (int)el);
+                // (with no ender lane 63 is a live lane that ran to the end of its subsequence: r_pos is where the next round starts)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // ---- 3. copy
+                // every store of earlier rounds (and blocks) has to be in L2 before a back-reference reads it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                const uint32_t trips = (nbytes + 63u) >> 6;
+                {   // the symbol that owns each byte: latest start at or before it
+                    uint32_t carry = 0;
+                    for (uint32_t tr = 0; tr < trips; tr++) {
+                        const uint32_t v = m.own[tr * 64u + lane];
+                        const uint32_t o = max(wave_scan_max_incl(v), carry);
+                        m.own[tr * 64u + lane] = (uint16_t)o;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t tr = 0; tr < trips; tr++) {
+                    const uint32_t j = opos_u + tr * 64u + lane;
+                    const bool inr = tr * 64u + lane < nbytes;
+                    uint2 sy = m.sym[inr ? (uint32_t)m.own[tr * 64u + lane] - 1u : 0u];
+                    bool lit = sy.x < 256u;
+                    uint32_t from = lit ? 0u : match_source(j, sy.y, sy.x & 0xffffu);
+                    // references into this round: through LDS, symbol by symbol, until a literal or older output
+                    while (__builtin_amdgcn_ballot_w64(inr && !lit && from >= opos_u)) {
+                        if (inr && !lit && from >= opos_u) {
+                            sy = m.sym[(uint32_t)m.own[from - opos_u] - 1u];
+                            lit = sy.x < 256u;
+                            if (!lit) from = match_source(from, sy.y, sy.x & 0xffffu);
+                        }
+                    }
+                    // older output was stored by this CU a moment ago: agent-scope (sc1) loads are served by L2 and
+                    // cannot hit a stale L1 line that was cached before the store
+                    if (inr) dst[j] = lit ? (uint8_t)sy.x : __hip_atomic_load(&dst[from], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                opos_u += nbytes;
+                bp = r_pos;
+                if (r_kind == kSyEob) { bp += r_nb; block_done = 1; }
+                else if (r_kind == kSyNeed) { stop_status = kInfNeedInput; block_done = 1; }
+                else if (r_kind == kSyData) { stop_status = kInfDataError; block_done = 1; }
+                else if (r_kind == kSyOverflow) { stop_status = kInfOverflow; block_done = 1; }
+                // kSyCut / kSyNone: the next round starts at bp
             }
             // hand the position back to lane 0's reader for the next block header
             uint32_t halt = 0;

@@ -75,12 +75,14 @@ def test_full_batch_at_bench_workspace_is_bit_identical(zwz, oracle, workload):
         try:
             d_out = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
             d_olen = torch.zeros(n, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()      # torch fills on ITS stream; the codec runs on its own (non-blocking) one
             c.deflate_dev(d_in, d_off, d_len, d_out, d_olen)
             c.sync()
             if max_batch == 51200:
                 d_back = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
                 d_blen = torch.zeros(n, dtype=torch.int32, device=dev)
                 d_stat = torch.zeros(n, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
                 c.inflate_dev(d_out, d_off, d_olen, d_back, d_blen, d_stat)
                 c.sync()
                 v = bench.verify_bytes(torch, d_in, d_len, d_olen, d_back, d_blen, d_stat)
@@ -287,7 +289,7 @@ def test_lossless_chunk_size_roundtrips_incompressible_files(zwz, oracle, tmp_pa
         c.set_chunk_size(0)
         b1, b2 = tmp_path / "b1", tmp_path / "b2"
         b1.mkdir(); b2.mkdir()
-        assert c.do_decompression(str(lossy), str(b1)) == 4                   # the reference's behaviour: four random files come back short
+        assert c.do_decompression(str(lossy), str(b1)) == 3                   # the reference's behaviour: r1, r3, r4 come back short (r2 = 65504 B just fits)
         assert c.do_decompression(str(loss_free), str(b2)) == 0
         for n, d in files.items():
             assert open(b2 / n, "rb").read() == d, n
