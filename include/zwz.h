@@ -43,7 +43,7 @@ extern "C" {
 #define ZWZ_CHUNK_SIZE 65535u      /* process.hpp:12 CHUNK_SIZE */
 #define ZWZ_DEV_STRIDE 65536u      /* chunk slot stride in device buffers (16-byte aligned slots) */
 #define ZWZ_MD5_HEX_LEN 32u        /* process.hpp:14 MD5_DATA_SIZE */
-#define ZWZ_LOSSLESS_CHUNK_SIZE 65504u /* opt-in: largest chunk whose stream always fits 65535 bytes */
+#define ZWZ_LOSSLESS_CHUNK_SIZE 65509u /* opt-in: largest chunk whose stream always fits 65535 bytes: 4 stored blocks, n + 26 */
 
 typedef enum zwz_status {
     ZWZ_OK = 0,
@@ -139,7 +139,7 @@ int zwz_decompress_dir_ranked(zwz_ctx *ctx, const char *src_dir, const char *dst
                               zwz_allgather_u64_fn exchange, void *user, int *md5_mismatches);
 
 /* Opt-in, never the default, NOT bit-exact with the reference's shards: raw bytes per Chunk for
- * zwz_compress_dir, 1..65535; 0 restores the reference's 65535 (process.hpp:12).  ZWZ_LOSSLESS_CHUNK_SIZE (65504) is the
+ * zwz_compress_dir, 1..65535; 0 restores the reference's 65535 (process.hpp:12).  ZWZ_LOSSLESS_CHUNK_SIZE (65509) is the
  * largest size whose level-6 stream always fits the reference's 65535-byte payload buffer (compression.cpp:127-132), so
  * nothing is truncated and every file round-trips with a matching MD5; the container is unchanged and the reference's
  * decoder reads such shards.  The environment variables ZWZ_LOSSLESS=1 / ZWZ_CHUNK_SIZE=<n> do the same for the CLI. */

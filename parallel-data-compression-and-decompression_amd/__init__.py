@@ -22,7 +22,7 @@ DEV_STRIDE = 65536
 NUM_STAGES = 7
 STAGE_NAMES = ("lz_links", "lz_match", "lz_parse", "blockify", "plan", "encode", "inflate")
 
-LOSSLESS_CHUNK_SIZE = 65504  # opt-in, never default (include/zwz.h: zwz_ctx_set_chunk_size)
+LOSSLESS_CHUNK_SIZE = 65509  # opt-in, never default (include/zwz.h: zwz_ctx_set_chunk_size)
 # zwz_allgather_u64_fn: int (*)(void *user, const uint64_t *mine, uint64_t *all, uint32_t count)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                 ctypes.c_uint32)

@@ -632,46 +632,99 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         // chains (lz_links' count, above) take the screening pass instead.
         const uint32_t npos = te - ts;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = lane_id();   // (the compiler does not see tid >> 6 as wave-uniform)
-        auto key_of = [&](uint32_t p) -> uint32_t {
-            if (p >= te || p + kMinMatch > L) return 7u;
-            const uint32_t l1 = slink[p - org];
-            if (l1 == 0 || p - l1 > kMaxDist) return 7u;
-            const uint32_t l2 = slink[l1 - org];
-            if (l2 == 0 || p - l2 > kMaxDist) return 7u;
-            const uint32_t lg = 31u - (uint32_t)__builtin_clz(p - l2);
-            return (lg > 13u ? 13u : lg) >> 1;
-        };
+        uint32_t nlist = npos;                                     // sorted order: positions on the work list (wave-uniform after the scan)
         if (sorted_order) {
-            // counts[bucket][trip][wave] -> exclusive scan -> destination of every position
-            for (uint32_t kk = 0; kk < 16u; kk++) {
-                const uint32_t key = key_of(ts + tid + kk * kMatchThreads);
-                const bool in = tid + kk * kMatchThreads < npos;
-                uint32_t mycnt = 0;
+            // The key is a prediction of how many candidates the walk will visit: the chain is followed for up to kKeyDepth
+            // links -- a chain that ends before that has exactly that many candidates; otherwise their density over the
+            // distance to the kKeyDepth-th one, extended over the window, estimates the rest (capped at zlib's 128) --
+            // quantised to 15 half-octave buckets.  A position whose first candidate is out of play (the test
+            // lz_search_wave starts with) has no record and is left off the list altogether: key 0.
+            // (Offline, on the text corpus: the second-predecessor key of round 1 gave 0.62 lane utilisation in the
+            // walk, this one 0.84, the true chain length 0.99; tools/exp/chain_keys.py.)
+            constexpr uint32_t kKeyDepth = 8;
+            uint32_t mykeys[2] = {0u, 0u}, myrank[4] = {0u, 0u, 0u, 0u};   // 16 positions a thread: 4-bit keys, 8-bit ranks
+            auto keys_of4 = [&](uint32_t q0, uint32_t key[4]) {       // positions ts + q0 + j * kMatchThreads: four chains in flight
+                uint32_t p[4], cur[4], cnt[4], lim[4], live[4];
 #pragma unroll
-                for (uint32_t b = 0; b < 8u; b++) { const uint32_t c = (uint32_t)__popcll(__ballot(in && key == b)); if (lane == b) mycnt = c; }
-                if (lane < 8u) s_cnt[(lane * 16u + kk) * 16u + wave] = (uint16_t)mycnt;
+                for (uint32_t j = 0; j < 4; j++) {
+                    p[j] = ts + q0 + j * kMatchThreads;
+                    const bool ok = p[j] < te && p[j] + kMinMatch <= L;
+                    const uint32_t l1 = slink[ok ? p[j] - org : 0u];
+                    live[j] = (uint32_t)(ok && l1 != 0 && p[j] - l1 <= kMaxDist && !(p[j] >= kSlidePos && l1 <= kWSize));
+                    cur[j] = live[j] ? l1 : (ok ? p[j] : org);         // (out of play: any readable position)
+                    cnt[j] = live[j];
+                    lim[j] = p[j] > kMaxDist ? p[j] - kMaxDist : 0u;
+                }
+#pragma unroll
+                for (uint32_t st = 1; st < kKeyDepth; st++) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t nx = slink[cur[j] - org];
+                        const uint32_t adv = live[j] & (uint32_t)(nx > lim[j]);
+                        cur[j] = adv ? nx : cur[j]; cnt[j] += adv; live[j] = adv;
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    float est = (float)cnt[j];
+                    if (cnt[j] == kKeyDepth) {
+                        const uint32_t win = p[j] < kMaxDist ? p[j] : kMaxDist;
+                        est = fminf(128.0f, (float)(win * kKeyDepth) * __frcp_rn((float)(p[j] - cur[j])));
+                        est = fmaxf(est, (float)kKeyDepth);
+                    }
+                    const uint32_t k = 1u + (uint32_t)(__log2f(fmaxf(est, 1.0f)) * 2.0f);
+                    key[j] = cnt[j] ? (k > 15u ? 15u : k) : 0u;
+                }
+            };
+            // One-hot byte per key in four dwords, add-scanned over the wave: a lane's own field of the scan is its rank among
+            // the wave's lanes with that key, lane 63's fields are the wave's counts (<= 64: a byte holds them).
+            auto wave_key_rank = [&](uint32_t key, uint32_t& rank, uint32_t& count_for_lane) {
+                const uint32_t one = key ? 1u << (8u * (key & 3u)) : 0u, word = key >> 2;
+                uint32_t inc[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) inc[i] = wave_scan_incl(word == i ? one : 0u);
+                const uint32_t mine = word == 0 ? inc[0] : word == 1 ? inc[1] : word == 2 ? inc[2] : inc[3];
+                rank = ((mine >> (8u * (key & 3u))) & 0xffu) - 1u;            // (meaningless for key 0: never used)
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)inc[0], 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)inc[1], 63);
+                const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)inc[2], 63), t3 = (uint32_t)__builtin_amdgcn_readlane((int)inc[3], 63);
+                const uint32_t lw = (lane >> 2) & 3u;
+                const uint32_t tw = lw == 0 ? t0 : lw == 1 ? t1 : lw == 2 ? t2 : t3;
+                count_for_lane = (tw >> (8u * (lane & 3u))) & 0xffu;         // lanes 0..15: the wave's count of key `lane`
+            };
+            // counts[key][trip][wave] -> exclusive scan -> destination of every listed position
+#pragma unroll
+            for (uint32_t kk0 = 0; kk0 < 16u; kk0 += 4u) {
+                uint32_t key[4];
+                keys_of4(tid + kk0 * kMatchThreads, key);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t kk = kk0 + j;
+                    uint32_t rank, cnt_lane;
+                    wave_key_rank(key[j], rank, cnt_lane);
+                    mykeys[kk >> 3] |= key[j] << (4u * (kk & 7u));
+                    myrank[kk >> 2] |= (rank & 0xffu) << (8u * (kk & 3u));
+                    if (lane < 16u) s_cnt[(lane * 16u + kk) * 16u + wave] = (uint16_t)cnt_lane;
+                }
             }
             __syncthreads();
-            {   // exclusive scan of the 2048 counts, two per thread
-                const uint32_t a = s_cnt[2 * tid], bb = s_cnt[2 * tid + 1];
-                uint32_t incl = a + bb;
-                for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            {   // exclusive scan of the 4096 counts, four per thread (key 0's are zero)
+                const uint2 c4 = *reinterpret_cast<const uint2*>(s_cnt + 4 * tid);
+                const uint32_t a = c4.x & 0xffffu, b = c4.x >> 16, c = c4.y & 0xffffu, d = c4.y >> 16;
+                const uint32_t own = a + b + c + d;
+                const uint32_t incl = wave_scan_incl(own);
                 if (lane == 63) s_wtot[wave] = incl;
                 __syncthreads();
-                uint32_t wbase = 0;
-                for (uint32_t i = 0; i < wave; i++) wbase += s_wtot[i];
-                const uint32_t ex = wbase + incl - a - bb;
-                s_cnt[2 * tid] = (uint16_t)ex; s_cnt[2 * tid + 1] = (uint16_t)(ex + a);
+                uint32_t wbase = 0, total = 0;
+                for (uint32_t i = 0; i < kMatchThreads / 64; i++) { const uint32_t w = s_wtot[i]; wbase += i < wave ? w : 0u; total += w; }
+                nlist = __builtin_amdgcn_readfirstlane(total);
+                const uint32_t ex = wbase + incl - own;
+                *reinterpret_cast<uint2*>(s_cnt + 4 * tid) = make_uint2(ex | (ex + a) << 16, (ex + a + b) | (ex + a + b + c) << 16);
             }
             __syncthreads();
-            for (uint32_t kk = 0; kk < 16u; kk++) {
-                const uint32_t q = tid + kk * kMatchThreads;
-                const uint32_t key = key_of(ts + q);
-                const bool in = q < npos;
-                uint32_t rank = 0;
 #pragma unroll
-                for (uint32_t b = 0; b < 8u; b++) { const uint64_t mk = __ballot(in && key == b); if (key == b) rank = rank_in(mk); }
-                if (in) perm[((uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank) & (kTile - 1u)] = (uint16_t)q;   // (< npos by construction; masked all the same)
+            for (uint32_t kk = 0; kk < 16u; kk++) {
+                const uint32_t key = (mykeys[kk >> 3] >> (4u * (kk & 7u))) & 15u, rank = (myrank[kk >> 2] >> (8u * (kk & 3u))) & 0xffu;
+                if (key) perm[((uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank) & (kTile - 1u)] = (uint16_t)(tid + kk * kMatchThreads);   // (< nlist by construction; masked all the same)
             }
             __syncthreads();
         }
@@ -686,8 +739,8 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         if (sorted_order) {
             for (uint32_t kk = 0; kk < 16u; kk++) {
                 const uint32_t idx = tid + kk * kMatchThreads;
-                if (__ballot(idx < npos) == 0) break;
-                search_and_store(idx < npos ? ts + (uint32_t)perm[idx] : ts, idx < npos);
+                if (__ballot(idx < nlist) == 0) break;
+                search_and_store(idx < nlist ? ts + (uint32_t)perm[idx] : ts, idx < nlist);
             }
         } else {
             // Sparse tile (incompressible data: a position has one predecessor in range on average, most

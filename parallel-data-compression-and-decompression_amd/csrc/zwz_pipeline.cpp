@@ -186,9 +186,10 @@ struct Drain {
 };
 
 // Raw bytes per Chunk.  process.hpp:12 fixes 65535 and the shards are bit-exact only with it (the default).  SURVEY.md
-// section 8 f4, opt-in and never default: ZWZ_LOSSLESS=1 cuts files every 65504 bytes instead -- the largest size whose level-6
-// stream always fits the reference's 65535-byte payload buffer (stored worst case: 2 + 5 blocks x 5 + 65504 + 4), so no
-// chunk is ever truncated and the round trip is exact; ZWZ_CHUNK_SIZE=<n <= 65535> sets any other size.  The container is
+// section 8 f4, opt-in and never default: ZWZ_LOSSLESS=1 cuts files every 65509 bytes instead -- the largest size whose level-6
+// stream always fits the reference's 65535-byte payload buffer (a chunk of fewer than 65533 bytes has at most 65532
+// symbols, i.e. at most 4 blocks; stored worst case: 2 + 4 x 5 + 65509 + 4 = 65535), so no chunk is ever truncated
+// and the round trip is exact; ZWZ_CHUNK_SIZE=<n <= 65535> sets any other size.  The container is
 // unchanged and the reference's own decoder reads such shards (it takes any chunk that decodes to <= 65535 bytes).
 uint32_t chunk_bytes_for(const zwz_ctx* c) {
     if (c->chunk_bytes) return c->chunk_bytes;

@@ -268,13 +268,13 @@ def test_cli_reports_a_failed_rank(tmp_path):
 
 # ---------------------------------------------------------------------------------------------- opt-in loss-free mode
 def test_lossless_chunk_size_roundtrips_incompressible_files(zwz, oracle, tmp_path):
-    """SURVEY.md section 8 f4, opt-in: with 65 504-byte chunks no level-6 stream exceeds the reference's 65 535-byte payload buffer
+    """SURVEY.md section 8 f4, opt-in: with 65 509-byte chunks no level-6 stream exceeds the reference's 65 535-byte payload buffer
     (compression.cpp:127-132), so incompressible files come back whole with a matching MD5 -- from this decoder AND from
     the reference's own, which reads the unchanged container.  The default stays bit-exact (every other test)."""
     src = tmp_path / "data" / "src"
     src.mkdir(parents=True)
-    files = {"r1.bin": corpus.random_bytes(71, 262144), "r2.bin": corpus.random_bytes(72, 65504), "r3.bin": corpus.random_bytes(73, 65535),
-             "r4.bin": corpus.random_bytes(74, 2 * 65504), "t.txt": corpus.text_like(75, 150000), "e.bin": b""}
+    files = {"r1.bin": corpus.random_bytes(71, 262144), "r2.bin": corpus.random_bytes(72, 65509), "r3.bin": corpus.random_bytes(73, 65535),
+             "r4.bin": corpus.random_bytes(74, 2 * 65509), "t.txt": corpus.text_like(75, 150000), "e.bin": b""}
     for n, d in files.items():
         (src / n).write_bytes(d)
     rec = tmp_path / "list.txt"
@@ -289,16 +289,16 @@ def test_lossless_chunk_size_roundtrips_incompressible_files(zwz, oracle, tmp_pa
         c.set_chunk_size(0)
         b1, b2 = tmp_path / "b1", tmp_path / "b2"
         b1.mkdir(); b2.mkdir()
-        assert c.do_decompression(str(lossy), str(b1)) == 3                   # the reference's behaviour: r1, r3, r4 come back short (r2 = 65504 B just fits)
+        assert c.do_decompression(str(lossy), str(b1)) == 3                   # the reference's behaviour: r1, r3, r4 come back short (r2 = 65509 B just fits)
         assert c.do_decompression(str(loss_free), str(b2)) == 0
         for n, d in files.items():
             assert open(b2 / n, "rb").read() == d, n
         import zwz_records
         recs = zwz_records.parse(open(loss_free / "compressed_0.zwz", "rb").read())
-        assert max(len(r[3]) for r in recs) == 65535 and [r[1] for r in recs if r[0] == b"r4.bin"] == [0, 1, 2]   # 65504 + 65504 + empty
-        for r in recs:                                                        # every payload is the oracle's stream of its 65 504-byte chunk
+        assert max(len(r[3]) for r in recs) == 65535 and [r[1] for r in recs if r[0] == b"r4.bin"] == [0, 1, 2]   # 65509 + 65509 + empty
+        for r in recs:                                                        # every payload is the oracle's stream of its 65 509-byte chunk
             data = files[r[0].decode()]
-            assert r[3] == oracle.payload(data[r[1] * 65504:(r[1] + 1) * 65504])
+            assert r[3] == oracle.payload(data[r[1] * 65509:(r[1] + 1) * 65509])
     finally:
         c.close()
     ref = os.path.join(ROOT, "oracle", "_ref", "main")
