@@ -12,7 +12,7 @@
 
 namespace zwz {
 
-constexpr uint32_t kLitFastBits = 10, kDistFastBits = 8;
+constexpr uint32_t kLitFastBits = 10, kDistFastBits = 10;   // (distance codes past 8 bits are common enough to matter: see lane_decode)
 constexpr uint32_t kBatch = 64;
 
 enum InflateStatus : uint32_t {
@@ -20,7 +20,8 @@ enum InflateStatus : uint32_t {
     kInfNeedInput = 1,  // payload ended early: truncated by the reference, or incomplete
     kInfDataError = 2,  // invalid stream
     kInfOverflow = 3,   // would produce more than the 65535-byte slot
-    kInfRunning = 4
+    kInfRunning = 4,
+    kInfPending = 5     // device only, between the two inflate kernels: a Huffman block was met, the chunk is still to be decoded
 };
 
 // Decoding tables of one block, built by lane 0 into LDS.
@@ -29,6 +30,7 @@ struct InflateTables {
     uint16_t dist_fast[1u << kDistFastBits];
     uint16_t lit_count[16], dist_count[16];  // canonical fallback: codes per length
     uint16_t lit_sym[288], dist_sym[32];     // symbols sorted by (length, symbol)
+    uint16_t lit_walk[2], dist_walk[2];      // canonical walk resumed behind the fast table: (first, index) at length fast_bits + 1
 };
 
 // LSB-first bit reader over payload bytes [0, n).  `in` is either the payload itself (mask = ~0)
@@ -83,7 +85,7 @@ struct BitReader {
 // Build fast + canonical tables from code lengths.  Returns 0 ok, -1 over-subscribed,
 // 1 incomplete (caller decides whether that is legal).  max_len receives the longest code.
 ZWZ_HD int build_decode_table(const uint8_t* lens, uint32_t n, uint16_t* fast, uint32_t fast_bits, uint16_t* count,
-                              uint16_t* sorted, uint32_t& max_len) {
+                              uint16_t* sorted, uint32_t& max_len, uint16_t* walk0 = nullptr) {
     uint16_t offs[16];
     for (uint32_t l = 0; l < 16; l++) count[l] = 0;
     for (uint32_t i = 0; i < n; i++) count[lens[i]]++;
@@ -94,6 +96,11 @@ ZWZ_HD int build_decode_table(const uint8_t* lens, uint32_t n, uint16_t* fast, u
         if (count[l]) max_len = l;
         left <<= 1; left -= count[l];
         if (left < 0) return -1;
+    }
+    if (walk0) {   // decode_symbol's walk after fast_bits lengths without a hit: its `first` and `index` do not depend on the bits
+        uint32_t first = 0, index = 0;
+        for (uint32_t l = 1; l <= fast_bits; l++) { index += count[l]; first += count[l]; first <<= 1; }
+        walk0[0] = (uint16_t)first; walk0[1] = (uint16_t)index;
     }
     offs[1] = 0;
     for (uint32_t l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
@@ -153,12 +160,26 @@ enum BlockKind : uint32_t { kBlkStored = 0, kBlkHuffman = 1, kBlkStop = 2 };
 // Read one block header.  Stored: returns kBlkStored with (src_off, len) = bytes to copy from
 // the payload (clipped to what the payload holds: a clipped stored block also sets status
 // NeedInput).  Huffman: tables are built, returns kBlkHuffman.  kBlkStop: status says why.
+// The header's first three bits (BFINAL, BTYPE); false (status set) if the payload ends inside them.
+ZWZ_HD bool inflate_block_type(InflateState& st, uint32_t& type) {
+    if (!st.br.take(1, st.last)) { st.status = kInfNeedInput; return false; }
+    if (!st.br.take(2, type)) { st.status = kInfNeedInput; return false; }
+    return true;
+}
+
+ZWZ_HD uint32_t inflate_block_rest(InflateState& st, InflateTables* tp, uint8_t* lens, uint32_t v, uint32_t& src_off, uint32_t& len);
+
 ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t* lens /* 320 B scratch */,
                                      uint32_t& src_off, uint32_t& len) {
-    BitReader& br = st.br;
     uint32_t v;
-    if (!br.take(1, st.last)) { st.status = kInfNeedInput; return kBlkStop; }
-    if (!br.take(2, v)) { st.status = kInfNeedInput; return kBlkStop; }
+    if (!inflate_block_type(st, v)) return kBlkStop;
+    return inflate_block_rest(st, &t, lens, v, src_off, len);
+}
+
+// Everything behind the type bits.  With tp == nullptr only stored blocks are handled: a Huffman block returns kBlkHuffman
+// with nothing built (the caller hands the chunk to the full decoder).
+ZWZ_HD uint32_t inflate_block_rest(InflateState& st, InflateTables* tp, uint8_t* lens, uint32_t v, uint32_t& src_off, uint32_t& len) {
+    BitReader& br = st.br;
     if (v == 0) {
         br.drop(br.bits & 7u);
         uint32_t a, b;
@@ -176,13 +197,15 @@ ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t
         return kBlkStored;
     }
     if (v == 3) { st.status = kInfDataError; return kBlkStop; }
+    if (!tp) return kBlkHuffman;
+    InflateTables& t = *tp;
     uint32_t nlen, ndist, max_len;
     if (v == 1) {
         nlen = 288; ndist = 30;
         for (uint32_t i = 0; i < 288; i++) lens[i] = (uint8_t)static_lit_len(i);
         for (uint32_t i = 0; i < 30; i++) lens[288 + i] = 5;
-        build_decode_table(lens, 288, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len);
-        build_decode_table(lens + 288, 30, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len);
+        build_decode_table(lens, 288, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len, t.lit_walk);
+        build_decode_table(lens + 288, 30, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len, t.dist_walk);
         return kBlkHuffman;
     }
     uint32_t ncode;
@@ -217,9 +240,9 @@ ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t
         while (rep--) lens[have++] = (uint8_t)prev;
     }
     if (lens[256] == 0) { st.status = kInfDataError; return kBlkStop; }
-    int lr = build_decode_table(lens, nlen, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len);
+    int lr = build_decode_table(lens, nlen, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len, t.lit_walk);
     if (lr < 0 || (lr > 0 && max_len != 1)) { st.status = kInfDataError; return kBlkStop; }
-    int dr = build_decode_table(lens + nlen, ndist, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len);
+    int dr = build_decode_table(lens + nlen, ndist, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len, t.dist_walk);
     if (dr < 0 || (dr > 0 && max_len > 1)) { st.status = kInfDataError; return kBlkStop; }
     return kBlkHuffman;
 }

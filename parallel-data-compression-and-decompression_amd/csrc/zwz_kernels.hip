@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             // (Offline, on the text corpus: the second-predecessor key of round 1 gave 0.62 lane utilisation in the
             // walk, this one 0.84, the true chain length 0.99; tools/exp/chain_keys.py.)
             constexpr uint32_t kKeyDepth = 8;
-            uint32_t mykeys[2] = {0u, 0u}, myrank[4] = {0u, 0u, 0u, 0u};   // 16 positions a thread: 4-bit keys, 8-bit ranks
+            uint64_t mykeys = 0, myrank_lo = 0, myrank_hi = 0;            // 16 positions a thread: 4-bit keys, 8-bit ranks
             auto keys_of4 = [&](uint32_t q0, uint32_t key[4]) {       // positions ts + q0 + j * kMatchThreads: four chains in flight
                 uint32_t p[4], cur[4], cnt[4], lim[4], live[4];
 #pragma unroll
@@ -692,7 +692,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 count_for_lane = (tw >> (8u * (lane & 3u))) & 0xffu;         // lanes 0..15: the wave's count of key `lane`
             };
             // counts[key][trip][wave] -> exclusive scan -> destination of every listed position
-#pragma unroll
+            // (rolled loops and packed state on purpose: unrolled, this phase's registers pushed the walk's into scratch and
+            // cost config 2 -- which never runs this code -- 3 ms)
+#pragma unroll 1
             for (uint32_t kk0 = 0; kk0 < 16u; kk0 += 4u) {
                 uint32_t key[4];
                 keys_of4(tid + kk0 * kMatchThreads, key);
@@ -701,8 +703,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     const uint32_t kk = kk0 + j;
                     uint32_t rank, cnt_lane;
                     wave_key_rank(key[j], rank, cnt_lane);
-                    mykeys[kk >> 3] |= key[j] << (4u * (kk & 7u));
-                    myrank[kk >> 2] |= (rank & 0xffu) << (8u * (kk & 3u));
+                    mykeys |= (uint64_t)key[j] << (4u * kk);
+                    const uint64_t r8 = (uint64_t)(rank & 0xffu) << (8u * (kk & 7u));
+                    if (kk0 < 8u) myrank_lo |= r8; else myrank_hi |= r8;
                     if (lane < 16u) s_cnt[(lane * 16u + kk) * 16u + wave] = (uint16_t)cnt_lane;
                 }
             }
@@ -721,9 +724,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 *reinterpret_cast<uint2*>(s_cnt + 4 * tid) = make_uint2(ex | (ex + a) << 16, (ex + a + b) | (ex + a + b + c) << 16);
             }
             __syncthreads();
-#pragma unroll
+#pragma unroll 1
             for (uint32_t kk = 0; kk < 16u; kk++) {
-                const uint32_t key = (mykeys[kk >> 3] >> (4u * (kk & 7u))) & 15u, rank = (myrank[kk >> 2] >> (8u * (kk & 3u))) & 0xffu;
+                const uint32_t key = (uint32_t)(mykeys >> (4u * kk)) & 15u, rank = (uint32_t)((kk < 8u ? myrank_lo : myrank_hi) >> (8u * (kk & 7u))) & 0xffu;
                 if (key) perm[((uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank) & (kTile - 1u)] = (uint16_t)(tid + kk * kMatchThreads);   // (< nlist by construction; masked all the same)
             }
             __syncthreads();
@@ -1752,43 +1755,51 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 // zlib's exact stopping behaviour: a symbol counts only if all of its bits are there, an error keeps what precedes it.
 // The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane, coalesced).
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
-constexpr uint32_t kSubBits = 32;          // bits of the stream per lane per round
-constexpr uint32_t kRoundSyms = 288;       // symbols a round can hold ...
-constexpr uint32_t kRoundBytes = 2048;     // ... and output bytes (a multiple of 64)
+constexpr uint32_t kSubBits = 64;          // bits of the stream per lane per round: a corrected start travels one lane a pass and lanes need
+                                           // up to ~200 bits to fall into step, so short subsequences mean many passes (32 bits: ~8)
+constexpr uint32_t kRoundSyms = 512;       // symbols a round can hold ...
+constexpr uint32_t kRoundBytes = 3072;     // ... and output bytes (a multiple of 64)
 static_assert(64 * kSubBits / 8 + 64 < kInfFill, "a round's window must fit what top_up keeps resident");
 
 struct InflateWaveMem {
     InflateTables t;
-    uint8_t lens[320];
     uint2 sym[kRoundSyms];                                      // (literal byte | len << 16 | dist, output position)
     __attribute__((aligned(16))) uint16_t own[kRoundBytes];     // per output byte of the round: 1 + index of the symbol that starts here, then of the one that owns it
+                                                                // (its first 320 bytes double as the block header's code-length scratch)
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
+static_assert(kRoundBytes * 2 >= 320, "code-length scratch lives in own[]");
+struct InflateStoredMem { __attribute__((aligned(16))) uint8_t ring[kInfRing + 16]; };   // the stored-only kernel: payload ring, nothing else
 
-enum : uint32_t { kSyLit = 0, kSyMatch = 1, kSyEob = 2, kSyNeed = 3, kSyData = 4, kSyOverflow = 5, kSyCut = 6, kSyNone = 7 };
+enum : uint32_t { kSyLit = 0, kSyMatch = 1, kSyEob = 2, kSyNeed = 3, kSyData = 4, kSyOverflow = 5, kSyCut = 6, kSySlow = 7, kSyNone = 8 };
 
-// Canonical walk for a code the fast table does not hold (inflate_core.h decode_symbol's slow path): 0 ok, kSyNeed, kSyData.
-static __device__ __forceinline__ uint32_t walk_code(const uint16_t* count, const uint16_t* sorted, uint64_t bits, int32_t avail,
-                                                     uint32_t& sym, uint32_t& len_out) {
-    int code = 0, first = 0, index = 0;
-    for (uint32_t len = 1; len <= 15; len++) {
-        if ((int32_t)len > avail) return kSyNeed;
+// Canonical walk for a code the fast table does not hold (inflate_core.h decode_symbol's slow path), resumed at the first
+// length the table does not cover: a miss means no shorter code matches, and the walk's `first` / `index` up to there do not
+// depend on the bits (build_decode_table stores them).  0 ok, kSyNeed, kSyData.  Rolled: at most five trips.
+static __device__ __forceinline__ uint32_t walk_code(const uint16_t* count, const uint16_t* sorted, const uint16_t* walk0, uint32_t fast_bits,
+                                                     uint64_t bits, int32_t avail, uint32_t& sym, uint32_t& len_out) {
+    int code = (int)((__brev((uint32_t)bits) >> (32u - fast_bits)) << 1), first = walk0[0], index = walk0[1];
+    uint32_t result = kSyData;
+    if (avail <= (int32_t)fast_bits) return kSyNeed;      // (no code of the lengths that are there matches: decode_symbol runs out of bits)
+#pragma unroll 1
+    for (uint32_t len = fast_bits + 1u; len <= 15u; len++) {
+        if ((int32_t)len > avail) { result = kSyNeed; break; }
         code |= (int)((bits >> (len - 1)) & 1u);
         const int c = count[len];
-        if (code - c < first) { sym = sorted[index + (code - first)]; len_out = len; return 0; }
+        if (code - c < first) { sym = sorted[index + (code - first)]; len_out = len; result = 0; break; }
         index += c; first += c; first <<= 1; code <<= 1;
     }
-    return kSyData;
+    return result;
 }
 
-// One symbol from a window of the stream (bit 0 = the symbol's first bit, >= 57 bits valid, `avail` of them payload).
-// Same decisions in the same order as inflate_decode_batch.
-static __device__ __forceinline__ uint32_t lane_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
+// One symbol from a window of the stream (bit 0 = the symbol's first bit, >= 57 bits valid, `avail` of them payload), with
+// every case zlib distinguishes, in inflate_decode_batch's order.  Run wave-uniformly, once, on the symbol a round stopped at.
+static __device__ __forceinline__ uint32_t careful_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
     nb = 0; val = 0;
     if (avail <= 0) return kSyNeed;
     const uint32_t e = t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
     uint32_t l = e & 15u, s = e >> 4;
-    if (e == 0) { const uint32_t r = walk_code(t.lit_count, t.lit_sym, bits, avail, s, l); if (r) return r; }
+    if (e == 0) { const uint32_t r = walk_code(t.lit_count, t.lit_sym, t.lit_walk, kLitFastBits, bits, avail, s, l); if (r) return r; }
     else if ((int32_t)l > avail) return kSyNeed;
     if (s < 256u) { nb = l; val = s; return kSyLit; }
     if (s == 256u) { nb = l; return kSyEob; }
@@ -1801,7 +1812,7 @@ static __device__ __forceinline__ uint32_t lane_decode(const InflateTables& t, u
     const int32_t avail2 = avail - (int32_t)(l + xb);
     const uint32_t de = t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
     uint32_t dl = de & 15u, d = de >> 4;
-    if (de == 0) { const uint32_t r = walk_code(t.dist_count, t.dist_sym, rest, avail2, d, dl); if (r) return r; }
+    if (de == 0) { const uint32_t r = walk_code(t.dist_count, t.dist_sym, t.dist_walk, kDistFastBits, rest, avail2, d, dl); if (r) return r; }
     else if ((int32_t)dl > avail2) return kSyNeed;
     if (d >= 30u) return kSyData;
     const uint32_t dxb = dist_extra_bits(d);
@@ -1809,6 +1820,35 @@ static __device__ __forceinline__ uint32_t lane_decode(const InflateTables& t, u
     const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
     nb = l + xb + dl + dxb; val = (len << 16) | dist;
     return kSyMatch;
+}
+
+// The same symbol without a branch, for the lanes of a round: two table reads and arithmetic.  What the fast tables cannot
+// settle -- a code past their index, an invalid code, a length or distance symbol out of range -- is kSySlow: the lane stops
+// there and careful_decode looks at that symbol when the round gets to it (on text about one symbol in a thousand; on the
+// garbage a lane reads before its start is corrected, more often -- it only has to stop).  A literal's or a match's bits
+// must all be there (kSyNeed otherwise), as zlib demands.  (Written with early returns this was ~200 instructions a
+// symbol, 40 % of them exec-mask bookkeeping.)
+static __device__ __forceinline__ uint32_t fast_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
+    const uint32_t e = t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
+    const uint32_t l = e & 15u, s = e >> 4;
+    const uint32_t c = s - 257u;                                       // (wraps for literals and end-of-block: unused then)
+    const bool is_len = s > 256u;
+    const uint32_t cc = c < 28u ? c : 28u;
+    const uint32_t xb = (cc < 8u || cc == 28u) ? 0u : (cc >> 2) - 1u;                              // length_extra_bits / length_base
+    const uint32_t lbase = cc < 8u ? cc : (cc == 28u ? 255u : ((4u + (cc & 3u)) << xb));
+    const uint32_t lx = l + xb;
+    const uint32_t len = lbase + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
+    const uint64_t rest = bits >> lx;
+    const uint32_t de = t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+    const uint32_t dl = de & 15u, dd = de >> 4, d = dd < 29u ? dd : 29u;
+    const uint32_t dxb = d < 4u ? 0u : (d >> 1) - 1u;                                             // dist_extra_bits / dist_base
+    const uint32_t dbase = d < 4u ? d : ((2u + (d & 1u)) << dxb);
+    const uint32_t dist = dbase + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
+    const uint32_t slow = (uint32_t)(e == 0u) | ((uint32_t)is_len & ((uint32_t)(c >= 29u) | (uint32_t)(de == 0u) | (uint32_t)(dd >= 30u)));
+    nb = is_len ? lx + dl + dxb : l;
+    val = is_len ? (len << 16) | dist : s;
+    const uint32_t kind = s < 256u ? kSyLit : (s == 256u ? kSyEob : kSyMatch);
+    return slow ? kSySlow : ((int32_t)nb > avail ? kSyNeed : kind);
 }
 
 static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {          // as wave_scan_incl, with max (0 = identity)
@@ -1821,40 +1861,131 @@ static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {     
     return v;
 }
 
-// byte `j` of a match that starts at output position p0 with distance d: where its value comes from
-static __device__ __forceinline__ uint32_t match_source(uint32_t j, uint32_t p0, uint32_t d) {
+// byte `j` of a match that starts at output position p0 with distance d: where its value comes from.  (The modulo only for
+// a match that overlaps itself -- a rare wave-uniform branch on text, the rule on run-length data.)
+static __device__ __forceinline__ uint32_t match_source(uint32_t j, uint32_t p0, uint32_t d, bool live) {
     const uint32_t off = j - p0;
-    return off < d ? j - d : p0 - d + off % d;
+    uint32_t from = j - d;
+    if (__builtin_amdgcn_ballot_w64(live && off >= d)) from = off < d ? from : p0 - d + off % d;
+    return from;
 }
 
-__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
-                                                                  const uint32_t* __restrict__ in_len, uint32_t n,
-                                                                  uint8_t* __restrict__ out, uint64_t out_stride,
-                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
-    __shared__ InflateWaveMem s_mem[kInflateThreads / 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = blockIdx.x * (kInflateThreads / 64) + wave;
-    if (chunk >= n) return;
-    InflateWaveMem& m = s_mem[wave];
-    const uint8_t* src = in + in_off[chunk];          // 16-byte aligned (API contract)
-    uint8_t* dst = out + (size_t)chunk * out_stride;
-    const uint32_t nin = in_len[chunk];
-    const uint32_t nin16 = (nin + 15u) & ~15u;         // readable extent (API contract)
-
-    uint32_t fill_end = 0;                             // ring holds payload bytes [fill_end - 2048, fill_end)
-    auto top_up = [&](uint32_t pos) {                  // wave-uniform: make [pos, pos + 1 KiB) resident
+// What both inflate kernels share: the payload ring and the stored-block copy.
+struct InflateIo {
+    const uint8_t* src; uint8_t* dst; uint8_t* ring; uint32_t nin16, lane, fill_end;
+    __device__ __forceinline__ void top_up(uint32_t pos) {             // wave-uniform: make [pos, pos + 1 KiB) resident
         pos = __builtin_amdgcn_readfirstlane(pos);
         if (fill_end + kInfRing < pos + kInfFill) fill_end = pos & ~(kInfFill - 1u);   // jumped (stored block): restart
         while (fill_end < pos + kInfFill && fill_end < nin16) {
             const uint32_t o = fill_end + lane * 16u;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (o < nin16) v = *reinterpret_cast<const uint4*>(src + o);
-            *reinterpret_cast<uint4*>(m.ring + (o & (kInfRing - 1u))) = v;
-            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(m.ring + kInfRing) = v;   // wrap-around mirror
+            *reinterpret_cast<uint4*>(ring + (o & (kInfRing - 1u))) = v;
+            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(ring + kInfRing) = v;   // wrap-around mirror
             fill_end += kInfFill;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
+    }
+    // stored bytes: whole 16-byte vectors of output, each from five aligned input words shifted by the two ranges' relative
+    // misalignment (a 5-byte block header sits between them); bytes at the ragged ends singly.
+    // (One byte per lane per trip moved 1.7 TB/s with 5 k waves in flight; this is ~10x fewer instructions.)
+    __device__ __forceinline__ void copy_stored(uint32_t soff, uint32_t opos, uint32_t cp) {
+        const uint32_t head = min(cp, (16u - (opos & 15u)) & 15u);               // dst + opos + head is 16-byte aligned (dst is)
+        if (lane < head) dst[opos + lane] = src[soff + lane];
+        const uint32_t s0 = soff + head, d0 = opos + head, sh = s0 & 3u;
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(src + (s0 & ~3u));
+        uint32_t nvec = (cp - head) >> 4;
+        while (nvec && (s0 & ~3u) + 16u * nvec + 4u > nin16) nvec--;            // the fifth word must lie inside the readable extent
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const uint32_t* q = sw + 4u * v;
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+            *reinterpret_cast<uint4*>(dst + d0 + 16u * v) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                                        __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+        }
+        for (uint32_t i = head + 16u * nvec + lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
+    }
+};
+
+// First of the two inflate kernels: chunks made of stored blocks only (incompressible data: every chunk).  Needs nothing but
+// the payload ring, so twenty waves fit a CU and the copy keeps its ~2 TB/s.  A chunk in which a Huffman block turns up goes
+// onto a list (work[0] = its length, work[2..] = chunk indices) for the second kernel, which starts it over.
+__global__ __launch_bounds__(kInflateStoredThreads) void inflate_stored_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                                const uint32_t* __restrict__ in_len, uint32_t n,
+                                                                                uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                                uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
+                                                                                uint32_t* __restrict__ work) {
+    __shared__ InflateStoredMem s_mem[kInflateStoredThreads / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t chunk = blockIdx.x * (kInflateStoredThreads / 64) + wave;
+    if (chunk >= n) return;
+    const uint32_t nin = in_len[chunk];
+    InflateIo io{in + in_off[chunk], out + (size_t)chunk * out_stride, s_mem[wave].ring, (nin + 15u) & ~15u, lane, 0u};
+    InflateState st;
+    io.top_up(0);
+    uint32_t go = 0;
+    if (lane == 0) go = inflate_begin(st, io.ring, nin, kInfRing - 1u) ? 1u : 0u;
+    go = __builtin_amdgcn_readfirstlane(go);
+    while (go) {
+        uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
+        io.top_up(st.br.pos);
+        if (lane == 0) {
+            uint32_t type = 0;
+            opos = st.out_pos;
+            kind = inflate_block_type(st, type) ? inflate_block_rest(st, nullptr, nullptr, type, soff, slen) : (uint32_t)kBlkStop;
+        }
+        kind = __builtin_amdgcn_readfirstlane(kind);
+        if (kind == kBlkHuffman) { if (lane == 0) work[2u + atomicAdd(&work[0], 1u)] = chunk; return; }   // onto the second kernel's list
+        if (kind == kBlkStop) break;
+        soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen); opos = __builtin_amdgcn_readfirstlane(opos);
+        const uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
+        io.copy_stored(soff, opos, cp);
+        uint32_t stop = 0;
+        if (lane == 0) {
+            st.out_pos += cp;
+            if (cp < slen) st.status = kInfOverflow;
+            if (st.status == kInfRunning && st.last) st.status = kInfEnd;
+            stop = st.status != kInfRunning;
+        }
+        if (__builtin_amdgcn_readfirstlane(stop)) break;
+    }
+    if (lane == 0) { out_len[chunk] = st.out_pos; status[chunk] = st.status; }
+}
+
+// Second kernel: the chunks on the first one's list, whole.  One wave per workgroup, as many workgroups as the chip holds at
+// once; a wave takes the next listed chunk until the list is empty (every wave reaches the end: the list is final when this
+// kernel starts, the cursor only grows).  (One workgroup per chunk cost 0.5 ms on incompressible data, where 50 000 of
+// them started only to find nothing to do.)
+static __device__ __forceinline__ void inflate_one_chunk(InflateWaveMem& m, uint32_t chunk, uint32_t lane, const uint8_t* __restrict__ in,
+                                                         const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ in_len,
+                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
+                                                         uint32_t* __restrict__ status);
+
+__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                  const uint32_t* __restrict__ in_len, uint32_t n,
+                                                                  uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
+                                                                  uint32_t* __restrict__ work) {
+    __shared__ InflateWaveMem s_mem;
+    static_assert(kInflateThreads == 64, "one wave per workgroup");
+    const uint32_t lane = lane_id();
+    const uint32_t listed = work[0];
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&work[1], 1u);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= listed) break;
+        const uint32_t chunk = work[2u + idx];
+        if (chunk < n) inflate_one_chunk(s_mem, chunk, lane, in, in_off, in_len, out, out_stride, out_len, status);
+    }
+}
+
+static __device__ __forceinline__ void inflate_one_chunk(InflateWaveMem& m, uint32_t chunk, uint32_t lane, const uint8_t* __restrict__ in,
+                                                         const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ in_len,
+                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
+                                                         uint32_t* __restrict__ status) {
+    uint8_t* dst = out + (size_t)chunk * out_stride;
+    const uint32_t nin = in_len[chunk];
+    InflateIo io{in + in_off[chunk], dst, m.ring, (nin + 15u) & ~15u, lane, 0u};
     auto window = [&](uint32_t a) -> uint64_t {        // the stream from bit a on: >= 57 bits
         const uint32_t byte = (a >> 3) & (kInfRing - 1u);
         const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
@@ -1863,38 +1994,21 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
     };
 
     InflateState st;
-    top_up(0);
+    io.top_up(0);
     uint32_t go = 0;
     if (lane == 0) go = inflate_begin(st, m.ring, nin, kInfRing - 1u) ? 1u : 0u;
     go = __builtin_amdgcn_readfirstlane(go);
     while (go) {
         uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
-        top_up(st.br.pos);
-        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, m.lens, soff, slen); }
+        io.top_up(st.br.pos);
+        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, reinterpret_cast<uint8_t*>(m.own), soff, slen); }
         kind = __builtin_amdgcn_readfirstlane(kind);
         if (kind == kBlkStop) break;
         if (kind == kBlkStored) {
             soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen);
             opos = __builtin_amdgcn_readfirstlane(opos);
-            uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
-            // stored bytes: whole 16-byte vectors of output, each from five aligned input words shifted by the two
-            // ranges' relative misalignment (a 5-byte block header sits between them); bytes at the ragged ends singly.
-            // (One byte per lane per trip moved 1.7 TB/s with 5 k waves in flight; this is ~10x fewer instructions.)
-            {
-                const uint32_t head = min(cp, (16u - (opos & 15u)) & 15u);               // dst + opos + head is 16-byte aligned (dst is)
-                if (lane < head) dst[opos + lane] = src[soff + lane];
-                const uint32_t s0 = soff + head, d0 = opos + head, sh = s0 & 3u;
-                const uint32_t* sw = reinterpret_cast<const uint32_t*>(src + (s0 & ~3u));
-                uint32_t nvec = (cp - head) >> 4;
-                while (nvec && (s0 & ~3u) + 16u * nvec + 4u > nin16) nvec--;            // the fifth word must lie inside the readable extent
-                for (uint32_t v = lane; v < nvec; v += 64) {
-                    const uint32_t* q = sw + 4u * v;
-                    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-                    *reinterpret_cast<uint4*>(dst + d0 + 16u * v) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                                                                                __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
-                }
-                for (uint32_t i = head + 16u * nvec + lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
-            }
+            const uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
+            io.copy_stored(soff, opos, cp);
             uint32_t stop = 0;
             if (lane == 0) {
                 st.out_pos += cp;
@@ -1910,33 +2024,33 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
             uint32_t block_done = 0, stop_status = kInfRunning;
             constexpr uint32_t kDead = 0xffffffffu;                       // "the stream does not get here this round"
             while (!block_done) {
-                top_up(bp >> 3);
+                io.top_up(bp >> 3);
                 // ---- 1. sync
                 const uint32_t bound = bp + kSubBits * (lane + 1u);
                 uint32_t start = bp + kSubBits * lane, endpos = 0, n_sym = 0, n_bytes = 0;
                 bool redo = true;
                 for (uint32_t pass = 0; pass < 64u; pass++) {
-                    if (redo) {
-                        uint32_t pos = start, ns = 0, nby = 0;
+                    {   // lanes whose start changed decode again; the loop body is predicated, not branched
+                        uint32_t pos = start == kDead ? bound : start, ns = 0, nby = 0;
                         bool stopped = start == kDead;
-                        for (;;) {
-                            const bool act = !stopped && pos < bound;
-                            if (__builtin_amdgcn_ballot_w64(redo && act) == 0) break;
-                            if (act) {
-                                uint32_t nb, val;
-                                const uint32_t k = lane_decode(m.t, window(pos), (int32_t)(total_bits - pos), nb, val);
-                                if (k <= kSyMatch) { ns++; nby += k == kSyLit ? 1u : val >> 16; pos += nb; }
-                                else stopped = true;
-                            }
+                        while (__builtin_amdgcn_ballot_w64(redo && !stopped && pos < bound)) {
+                            uint32_t nb, val;
+                            const uint32_t k = fast_decode(m.t, window(pos), (int32_t)(total_bits - pos), nb, val);
+                            const bool act = redo && !stopped && pos < bound;
+                            const bool plain = k <= kSyMatch;
+                            ns += (uint32_t)(act && plain);
+                            nby += act && plain ? (k == kSyLit ? 1u : val >> 16) : 0u;
+                            pos += act && plain ? nb : 0u;
+                            stopped = stopped || (act && !plain);
                         }
-                        endpos = stopped ? kDead : pos; n_sym = ns; n_bytes = nby;
+                        if (redo) { endpos = stopped ? kDead : pos; n_sym = ns; n_bytes = nby; }
                     }
                     uint32_t from_left = (uint32_t)__builtin_amdgcn_update_dpp((int)bp, (int)endpos, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps bp
                     if (lane == 0) from_left = bp;
                     redo = from_left != start;
                     start = from_left;
                     // Only the lanes up to the first one whose subsequence ends the round matter (an end of block, an
-                    // error, the payload's end): once THEIR starts agree with their left neighbours the sequence up to
+                    // oddity, the payload's end): once THEIR starts agree with their left neighbours the sequence up to
                     // that point is final, and what the lanes behind it hold is never looked at.  (Without this the "dead"
                     // mark would walk to lane 63 one lane a pass at the end of every block.)
                     const uint64_t enders = __builtin_amdgcn_ballot_w64(endpos == kDead);
@@ -1950,36 +2064,35 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
                 for (uint32_t i = lane; i < kRoundBytes / 8u; i += 64u) reinterpret_cast<uint4*>(m.own)[i] = make_uint4(0, 0, 0, 0);
                 const uint32_t sidx = wave_scan_incl(n_sym) - n_sym, ooff = wave_scan_incl(n_bytes) - n_bytes;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t e_kind = kSyNone, e_pos = start == kDead ? 0u : start, e_nb = 0, e_syms = 0, e_bytes = 0;
+                uint32_t e_kind = kSyNone, e_pos = start == kDead ? bound : start, e_nb = 0, e_syms = 0, e_bytes = 0;
                 {
                     bool stopped = start == kDead;
-                    for (;;) {
+                    while (__builtin_amdgcn_ballot_w64(!stopped && e_pos < bound)) {
+                        uint32_t nb, val;
+                        uint32_t k = fast_decode(m.t, window(e_pos), (int32_t)(total_bits - e_pos), nb, val);
                         const bool act = !stopped && e_pos < bound;
-                        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-                        if (act) {
-                            uint32_t nb, val;
-                            uint32_t k = lane_decode(m.t, window(e_pos), (int32_t)(total_bits - e_pos), nb, val);
-                            const uint32_t p = opos_u + ooff + e_bytes, si = sidx + e_syms;
-                            const uint32_t blen = k == kSyLit ? 1u : val >> 16;
-                            if (k <= kSyMatch) {
-                                if (k == kSyMatch && (val & 0xffffu) > p) k = kSyData;                 // too far back
-                                else if (p + blen > kChunk) k = kSyOverflow;
-                                else if (si >= kRoundSyms || p + blen - opos_u > kRoundBytes) k = kSyCut;   // the round is full: the next one starts here
-                            }
-                            if (k <= kSyMatch) {
-                                m.sym[si] = make_uint2(val, p);
-                                m.own[p - opos_u] = (uint16_t)(si + 1u);
-                                e_syms++; e_bytes += blen; e_pos += nb;
-                            } else { e_kind = k; e_nb = nb; stopped = true; }
+                        const uint32_t p = opos_u + ooff + e_bytes, si = sidx + e_syms;
+                        const uint32_t blen = k == kSyLit ? 1u : val >> 16;
+                        // what the symbol's place in the output decides: too far back, past the 65535-byte cap, round full
+                        k = k == kSyMatch && (val & 0xffffu) > p ? kSyData : k;
+                        k = k <= kSyMatch && p + blen > kChunk ? kSyOverflow : k;
+                        k = k <= kSyMatch && (si >= kRoundSyms || p + blen - opos_u > kRoundBytes) ? kSyCut : k;   // the next round starts here
+                        const bool plain = act && k <= kSyMatch;
+                        if (plain) {
+                            m.sym[si] = make_uint2(val, p);
+                            m.own[p - opos_u] = (uint16_t)(si + 1u);
                         }
+                        e_syms += (uint32_t)plain; e_bytes += plain ? blen : 0u; e_pos += plain ? nb : 0u;
+                        if (act && !plain) { e_kind = k; e_nb = nb; }
+                        stopped = stopped || (act && !plain);
                     }
                 }
                 // the round ends at the first lane, in stream order, that met something other than a plain symbol
                 const uint64_t enders = __builtin_amdgcn_ballot_w64(e_kind != kSyNone);
                 const uint32_t el = enders ? (uint32_t)__builtin_ctzll(enders) : 63u;
-                const uint32_t r_kind = enders ? (uint32_t)__builtin_amdgcn_readlane((int)e_kind, (int)el) : kSyNone;
+                uint32_t r_kind = enders ? (uint32_t)__builtin_amdgcn_readlane((int)e_kind, (int)el) : kSyNone;
                 const uint32_t r_pos = (uint32_t)__builtin_amdgcn_readlane((int)e_pos, (int)el);
-                const uint32_t r_nb = (uint32_t)__builtin_amdgcn_readlane((int)e_nb, (int)el);
+                uint32_t r_nb = (uint32_t)__builtin_amdgcn_readlane((int)e_nb, (int)el);
                 const uint32_t nbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + e_bytes), (int)el);
                 // (with no ender lane 63 is a live lane that ran to the end of its subsequence: r_pos is where the next round starts)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2003,14 +2116,13 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
                     const bool inr = tr * 64u + lane < nbytes;
                     uint2 sy = m.sym[inr ? (uint32_t)m.own[tr * 64u + lane] - 1u : 0u];
                     bool lit = sy.x < 256u;
-                    uint32_t from = lit ? 0u : match_source(j, sy.y, sy.x & 0xffffu);
+                    uint32_t from = match_source(j, sy.y, sy.x & 0xffffu, inr && !lit);
                     // references into this round: through LDS, symbol by symbol, until a literal or older output
                     while (__builtin_amdgcn_ballot_w64(inr && !lit && from >= opos_u)) {
-                        if (inr && !lit && from >= opos_u) {
-                            sy = m.sym[(uint32_t)m.own[from - opos_u] - 1u];
-                            lit = sy.x < 256u;
-                            if (!lit) from = match_source(from, sy.y, sy.x & 0xffffu);
-                        }
+                        const bool hop = inr && !lit && from >= opos_u;
+                        const uint2 s2 = m.sym[hop ? (uint32_t)m.own[from - opos_u] - 1u : 0u];
+                        const uint32_t f2 = match_source(from, s2.y, s2.x & 0xffffu, hop && s2.x >= 256u);
+                        if (hop) { sy = s2; lit = s2.x < 256u; from = lit ? from : f2; }
                     }
                     // older output was stored by this CU a moment ago: agent-scope (sc1) loads are served by L2 and
                     // cannot hit a stale L1 line that was cached before the store
@@ -2018,11 +2130,26 @@ __global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t*
                 }
                 opos_u += nbytes;
                 bp = r_pos;
+                if (r_kind == kSySlow) {
+                    // the fast tables could not settle this symbol: every lane decodes it with the full rules (wave-uniform)
+                    uint32_t val;
+                    r_kind = careful_decode(m.t, window(bp), (int32_t)(total_bits - bp), r_nb, val);
+                    if (r_kind == kSyMatch && (val & 0xffffu) > opos_u) r_kind = kSyData;
+                    else if (r_kind <= kSyMatch && opos_u + (r_kind == kSyLit ? 1u : val >> 16) > kChunk) r_kind = kSyOverflow;
+                    if (r_kind == kSyLit) { if (lane == 0) dst[opos_u] = (uint8_t)val; opos_u += 1u; bp += r_nb; }
+                    else if (r_kind == kSyMatch) {
+                        const uint32_t len = val >> 16, dist = val & 0xffffu, from = opos_u - dist;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this round's stores first
+                        __builtin_amdgcn_s_waitcnt(0);
+                        for (uint32_t i = lane; i < len; i += 64) dst[opos_u + i] = __hip_atomic_load(&dst[from + (i % dist)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        opos_u += len; bp += r_nb;
+                    }
+                }
                 if (r_kind == kSyEob) { bp += r_nb; block_done = 1; }
                 else if (r_kind == kSyNeed) { stop_status = kInfNeedInput; block_done = 1; }
                 else if (r_kind == kSyData) { stop_status = kInfDataError; block_done = 1; }
                 else if (r_kind == kSyOverflow) { stop_status = kInfOverflow; block_done = 1; }
-                // kSyCut / kSyNone: the next round starts at bp
+                // kSyLit / kSyMatch (settled above) / kSyCut / kSyNone: the next round starts at bp
             }
             // hand the position back to lane 0's reader for the next block header
             uint32_t halt = 0;
@@ -2227,9 +2354,14 @@ hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uin
 
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    const uint32_t per = kInflateThreads / 64;
-    hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
-                       a.out_stride, a.out_len, a.status);
+    // stored-only chunks in a kernel of their own (ring only: 20 waves a CU); what it leaves (kInfPending) to the full decoder
+    const uint32_t per_s = kInflateStoredThreads / 64;
+    ZWZ_TRY(hipMemsetAsync(a.work, 0, 2 * sizeof(uint32_t), s));          // list length, cursor
+    hipLaunchKernelGGL(inflate_stored_kernel, dim3((a.n + per_s - 1) / per_s), dim3(kInflateStoredThreads), 0, s, a.in, a.in_off, a.in_len, a.n,
+                       a.out, a.out_stride, a.out_len, a.status, a.work);
+    const uint32_t resident = a.resident_waves ? a.resident_waves : 2304u;
+    hipLaunchKernelGGL(inflate_kernel, dim3(a.n < resident ? a.n : resident), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
+                       a.out_stride, a.out_len, a.status, a.work);
     return hipGetLastError();
 }
 
