@@ -12,7 +12,7 @@
 
 namespace zwz {
 
-constexpr uint32_t kLitFastBits = 10, kDistFastBits = 10;   // (distance codes past 8 bits are common enough to matter: see lane_decode)
+constexpr uint32_t kLitFastBits = 10, kDistFastBits = 8;
 constexpr uint32_t kBatch = 64;
 
 enum InflateStatus : uint32_t {

@@ -91,7 +91,6 @@ void zwz_ctx_destroy(zwz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->workspace) (void)hipFree(c->workspace);
-    if (c->inf_work) (void)hipFree(c->inf_work);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -169,13 +168,7 @@ int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
     if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len || !d_status))) return ZWZ_E_INVALID;
     if (out_stride < ZWZ_CHUNK_SIZE || ((uintptr_t)d_in & 15u)) return ZWZ_E_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    if (n > c->inf_work_chunks) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->inf_work) { (void)hipFree(c->inf_work); c->inf_work = nullptr; c->inf_work_chunks = 0; }
-        HIPCHK(hipMalloc(&c->inf_work, ((size_t)n + 2) * sizeof(uint32_t)));
-        c->inf_work_chunks = n;
-    }
-    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status, static_cast<uint32_t*>(c->inf_work), c->cu_count * kInflateWavesPerCu};
+    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status};
     if (c->profiling) HIPCHK(hipEventRecord(c->ev_inf[0], c->stream));
     HIPCHK(launch_inflate(a, c->stream));
     if (c->profiling) {

@@ -15,8 +15,6 @@ struct zwz_ctx {
     void* d_stage = nullptr;
     void* h_stage = nullptr;
     uint32_t stage_chunks = 0;
-    void* inf_work = nullptr;        // inflate's list of chunks with Huffman blocks (InflateArgs::work)
-    uint32_t inf_work_chunks = 0;
     uint32_t cu_count = 0;
     uint32_t chunk_bytes = 0;        // raw bytes per Chunk for zwz_compress_dir; 0 = default (see chunk_bytes_for)
     bool profiling = false;

@@ -24,8 +24,7 @@ constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
 constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + kMaskWords * 8 + kMaskWords * 2 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 80496: two workgroups per CU
-constexpr uint32_t kInflateStoredThreads = 256;                 // stored-only chunks: four waves (2 KB of LDS each) per workgroup
-constexpr uint32_t kInflateThreads = 64;                        // one chunk (one wave, ~12 KB of LDS) per workgroup: 13 per CU
+constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
 constexpr int kNumDeflateStages = 6;
 
 struct ChunkInfo { uint32_t n_sym, n_blocks; };
@@ -79,10 +78,7 @@ struct DeflateArgs {
 struct InflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;
     uint8_t* out; uint64_t out_stride; uint32_t* out_len; uint32_t* status;
-    uint32_t* work;            // n + 2 words: the list the stored-only kernel leaves for the full decoder (length, cursor, chunk indices)
-    uint32_t resident_waves;   // workgroups of the full decoder the device holds at once (CUs x 9)
 };
-constexpr uint32_t kInflateWavesPerCu = 9;   // InflateWaveMem is ~17 KB of the CU's 160 KB
 
 constexpr size_t kWorkspaceBytesPerChunk =
     (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) +

@@ -1732,283 +1732,86 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// inflate: one wave per chunk.  Lane 0 owns block headers and table construction; the symbols of a Huffman block are
-// decoded by the whole wave, a ROUND at a time, and the wave moves the bytes.
-//
-// Decoding is sequential only in where symbols START.  A round looks at the next 64 x kSubBits bits of the stream, one
-// subsequence per lane (self-synchronising parallel Huffman decoding):
-//   1. sync   every lane decodes symbol after symbol from its start until it crosses into the next lane's
-//             subsequence, and hands the bit position it ends at to that lane as its corrected start.  Lane 0's start
-//             is exact; a lane that started inside a symbol usually falls into step with the true sequence within a few
-//             symbols, so its END is right long before its start is.  Repeated until no start changes (2-4 times on
-//             text; never more than 64: after k passes lanes 0..k-1 are final).
-//   2. emit   symbol and byte counts per lane -> exclusive prefix sums -> every symbol's index and output position; one
-//             more pass with values writes (value, position) per symbol and marks each symbol's first output byte.
-//             Whatever ends the round is found here, in stream order: end of block, an invalid or incomplete code, a
-//             distance beyond the output, the 65535-byte cap, or simply the round's capacity.
-//   3. copy   byte-parallel: a max-scan over the marks names the symbol that owns each output byte; back-references into
-//             the round itself are chased through LDS; everything older is in global memory, every store of an earlier
-//             round drained.  64 bytes per trip, coalesced stores.
-// The round-1 kernel decoded at EVERY bit offset of a 256-bit window (one real symbol per ~9 speculative decodes, ~38
-// wave instructions per symbol, a 6-step owner search per output byte); a lane now decodes a handful of symbols in a row.
-// Codes longer than the fast tables are walked canonically by the lane that meets one (no sequential fallback), with
-// zlib's exact stopping behaviour: a symbol counts only if all of its bits are there, an error keeps what precedes it.
-// The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane, coalesced).
+// inflate: one wave per chunk.  Lane 0 owns block headers and table construction; symbols are decoded by the
+// whole wave from a window of the bit stream (see the Huffman branch below) and the wave moves the bytes.
+// The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane,
+// coalesced): a round consumes < 1 KiB, so topping the ring up to pos + 1 KiB before every round keeps the
+// decoders off global memory entirely.
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
-constexpr uint32_t kSubBits = 64;          // bits of the stream per lane per round: a corrected start travels one lane a pass and lanes need
-                                           // up to ~200 bits to fall into step, so short subsequences mean many passes (32 bits: ~8)
-constexpr uint32_t kRoundSyms = 512;       // symbols a round can hold ...
-constexpr uint32_t kRoundBytes = 3072;     // ... and output bytes (a multiple of 64)
-static_assert(64 * kSubBits / 8 + 64 < kInfFill, "a round's window must fit what top_up keeps resident");
+constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
 
 struct InflateWaveMem {
     InflateTables t;
-    uint2 sym[kRoundSyms];                                      // (literal byte | len << 16 | dist, output position)
-    __attribute__((aligned(16))) uint16_t own[kRoundBytes];     // per output byte of the round: 1 + index of the symbol that starts here, then of the one that owns it
-                                                                // (its first 320 bytes double as the block header's code-length scratch)
+    uint8_t lens[320];
+    uint32_t batch[kBatch], pos[kBatch];
+    uint16_t jump[64 * kWinSlots + 8];       // window offset -> offset of the symbol after the one starting there (pointer doubling)
+    uint32_t flag[64 * kWinSlots / 4];       // one byte per window offset: reached from offset 0
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
-static_assert(kRoundBytes * 2 >= 320, "code-length scratch lives in own[]");
-struct InflateStoredMem { __attribute__((aligned(16))) uint8_t ring[kInfRing + 16]; };   // the stored-only kernel: payload ring, nothing else
 
-enum : uint32_t { kSyLit = 0, kSyMatch = 1, kSyEob = 2, kSyNeed = 3, kSyData = 4, kSyOverflow = 5, kSyCut = 6, kSySlow = 7, kSyNone = 8 };
+__global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                  const uint32_t* __restrict__ in_len, uint32_t n,
+                                                                  uint8_t* __restrict__ out, uint64_t out_stride,
+                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
+    __shared__ InflateWaveMem s_mem[kInflateThreads / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t chunk = blockIdx.x * (kInflateThreads / 64) + wave;
+    if (chunk >= n) return;
+    InflateWaveMem& m = s_mem[wave];
+    const uint8_t* src = in + in_off[chunk];          // 16-byte aligned (API contract)
+    uint8_t* dst = out + (size_t)chunk * out_stride;
+    const uint32_t nin = in_len[chunk];
+    const uint32_t nin16 = (nin + 15u) & ~15u;         // readable extent (API contract)
 
-// Canonical walk for a code the fast table does not hold (inflate_core.h decode_symbol's slow path), resumed at the first
-// length the table does not cover: a miss means no shorter code matches, and the walk's `first` / `index` up to there do not
-// depend on the bits (build_decode_table stores them).  0 ok, kSyNeed, kSyData.  Rolled: at most five trips.
-static __device__ __forceinline__ uint32_t walk_code(const uint16_t* count, const uint16_t* sorted, const uint16_t* walk0, uint32_t fast_bits,
-                                                     uint64_t bits, int32_t avail, uint32_t& sym, uint32_t& len_out) {
-    int code = (int)((__brev((uint32_t)bits) >> (32u - fast_bits)) << 1), first = walk0[0], index = walk0[1];
-    uint32_t result = kSyData;
-    if (avail <= (int32_t)fast_bits) return kSyNeed;      // (no code of the lengths that are there matches: decode_symbol runs out of bits)
-#pragma unroll 1
-    for (uint32_t len = fast_bits + 1u; len <= 15u; len++) {
-        if ((int32_t)len > avail) { result = kSyNeed; break; }
-        code |= (int)((bits >> (len - 1)) & 1u);
-        const int c = count[len];
-        if (code - c < first) { sym = sorted[index + (code - first)]; len_out = len; result = 0; break; }
-        index += c; first += c; first <<= 1; code <<= 1;
-    }
-    return result;
-}
-
-// One symbol from a window of the stream (bit 0 = the symbol's first bit, >= 57 bits valid, `avail` of them payload), with
-// every case zlib distinguishes, in inflate_decode_batch's order.  Run wave-uniformly, once, on the symbol a round stopped at.
-static __device__ __forceinline__ uint32_t careful_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
-    nb = 0; val = 0;
-    if (avail <= 0) return kSyNeed;
-    const uint32_t e = t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
-    uint32_t l = e & 15u, s = e >> 4;
-    if (e == 0) { const uint32_t r = walk_code(t.lit_count, t.lit_sym, t.lit_walk, kLitFastBits, bits, avail, s, l); if (r) return r; }
-    else if ((int32_t)l > avail) return kSyNeed;
-    if (s < 256u) { nb = l; val = s; return kSyLit; }
-    if (s == 256u) { nb = l; return kSyEob; }
-    const uint32_t c = s - 257u;
-    if (c >= 29u) return kSyData;
-    const uint32_t xb = length_extra_bits(c);
-    if ((int32_t)(l + xb) > avail) return kSyNeed;
-    const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
-    const uint64_t rest = bits >> (l + xb);
-    const int32_t avail2 = avail - (int32_t)(l + xb);
-    const uint32_t de = t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
-    uint32_t dl = de & 15u, d = de >> 4;
-    if (de == 0) { const uint32_t r = walk_code(t.dist_count, t.dist_sym, t.dist_walk, kDistFastBits, rest, avail2, d, dl); if (r) return r; }
-    else if ((int32_t)dl > avail2) return kSyNeed;
-    if (d >= 30u) return kSyData;
-    const uint32_t dxb = dist_extra_bits(d);
-    if ((int32_t)(dl + dxb) > avail2) return kSyNeed;
-    const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
-    nb = l + xb + dl + dxb; val = (len << 16) | dist;
-    return kSyMatch;
-}
-
-// The same symbol without a branch, for the lanes of a round: two table reads and arithmetic.  What the fast tables cannot
-// settle -- a code past their index, an invalid code, a length or distance symbol out of range -- is kSySlow: the lane stops
-// there and careful_decode looks at that symbol when the round gets to it (on text about one symbol in a thousand; on the
-// garbage a lane reads before its start is corrected, more often -- it only has to stop).  A literal's or a match's bits
-// must all be there (kSyNeed otherwise), as zlib demands.  (Written with early returns this was ~200 instructions a
-// symbol, 40 % of them exec-mask bookkeeping.)
-static __device__ __forceinline__ uint32_t fast_decode(const InflateTables& t, uint64_t bits, int32_t avail, uint32_t& nb, uint32_t& val) {
-    const uint32_t e = t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
-    const uint32_t l = e & 15u, s = e >> 4;
-    const uint32_t c = s - 257u;                                       // (wraps for literals and end-of-block: unused then)
-    const bool is_len = s > 256u;
-    const uint32_t cc = c < 28u ? c : 28u;
-    const uint32_t xb = (cc < 8u || cc == 28u) ? 0u : (cc >> 2) - 1u;                              // length_extra_bits / length_base
-    const uint32_t lbase = cc < 8u ? cc : (cc == 28u ? 255u : ((4u + (cc & 3u)) << xb));
-    const uint32_t lx = l + xb;
-    const uint32_t len = lbase + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
-    const uint64_t rest = bits >> lx;
-    const uint32_t de = t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
-    const uint32_t dl = de & 15u, dd = de >> 4, d = dd < 29u ? dd : 29u;
-    const uint32_t dxb = d < 4u ? 0u : (d >> 1) - 1u;                                             // dist_extra_bits / dist_base
-    const uint32_t dbase = d < 4u ? d : ((2u + (d & 1u)) << dxb);
-    const uint32_t dist = dbase + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
-    const uint32_t slow = (uint32_t)(e == 0u) | ((uint32_t)is_len & ((uint32_t)(c >= 29u) | (uint32_t)(de == 0u) | (uint32_t)(dd >= 30u)));
-    nb = is_len ? lx + dl + dxb : l;
-    val = is_len ? (len << 16) | dist : s;
-    const uint32_t kind = s < 256u ? kSyLit : (s == 256u ? kSyEob : kSyMatch);
-    return slow ? kSySlow : ((int32_t)nb > avail ? kSyNeed : kind);
-}
-
-static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {          // as wave_scan_incl, with max (0 = identity)
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
-    return v;
-}
-
-// byte `j` of a match that starts at output position p0 with distance d: where its value comes from.  (The modulo only for
-// a match that overlaps itself -- a rare wave-uniform branch on text, the rule on run-length data.)
-static __device__ __forceinline__ uint32_t match_source(uint32_t j, uint32_t p0, uint32_t d, bool live) {
-    const uint32_t off = j - p0;
-    uint32_t from = j - d;
-    if (__builtin_amdgcn_ballot_w64(live && off >= d)) from = off < d ? from : p0 - d + off % d;
-    return from;
-}
-
-// What both inflate kernels share: the payload ring and the stored-block copy.
-struct InflateIo {
-    const uint8_t* src; uint8_t* dst; uint8_t* ring; uint32_t nin16, lane, fill_end;
-    __device__ __forceinline__ void top_up(uint32_t pos) {             // wave-uniform: make [pos, pos + 1 KiB) resident
+    uint32_t fill_end = 0;                             // ring holds payload bytes [fill_end - 2048, fill_end)
+    auto top_up = [&](uint32_t pos) {                  // wave-uniform: make [pos, pos + 1 KiB) resident
         pos = __builtin_amdgcn_readfirstlane(pos);
         if (fill_end + kInfRing < pos + kInfFill) fill_end = pos & ~(kInfFill - 1u);   // jumped (stored block): restart
         while (fill_end < pos + kInfFill && fill_end < nin16) {
             const uint32_t o = fill_end + lane * 16u;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (o < nin16) v = *reinterpret_cast<const uint4*>(src + o);
-            *reinterpret_cast<uint4*>(ring + (o & (kInfRing - 1u))) = v;
-            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(ring + kInfRing) = v;   // wrap-around mirror
+            *reinterpret_cast<uint4*>(m.ring + (o & (kInfRing - 1u))) = v;
+            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(m.ring + kInfRing) = v;   // wrap-around mirror
             fill_end += kInfFill;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    // stored bytes: whole 16-byte vectors of output, each from five aligned input words shifted by the two ranges' relative
-    // misalignment (a 5-byte block header sits between them); bytes at the ragged ends singly.
-    // (One byte per lane per trip moved 1.7 TB/s with 5 k waves in flight; this is ~10x fewer instructions.)
-    __device__ __forceinline__ void copy_stored(uint32_t soff, uint32_t opos, uint32_t cp) {
-        const uint32_t head = min(cp, (16u - (opos & 15u)) & 15u);               // dst + opos + head is 16-byte aligned (dst is)
-        if (lane < head) dst[opos + lane] = src[soff + lane];
-        const uint32_t s0 = soff + head, d0 = opos + head, sh = s0 & 3u;
-        const uint32_t* sw = reinterpret_cast<const uint32_t*>(src + (s0 & ~3u));
-        uint32_t nvec = (cp - head) >> 4;
-        while (nvec && (s0 & ~3u) + 16u * nvec + 4u > nin16) nvec--;            // the fifth word must lie inside the readable extent
-        for (uint32_t v = lane; v < nvec; v += 64) {
-            const uint32_t* q = sw + 4u * v;
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-            *reinterpret_cast<uint4*>(dst + d0 + 16u * v) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                                                                        __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
-        }
-        for (uint32_t i = head + 16u * nvec + lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
-    }
-};
-
-// First of the two inflate kernels: chunks made of stored blocks only (incompressible data: every chunk).  Needs nothing but
-// the payload ring, so twenty waves fit a CU and the copy keeps its ~2 TB/s.  A chunk in which a Huffman block turns up goes
-// onto a list (work[0] = its length, work[2..] = chunk indices) for the second kernel, which starts it over.
-__global__ __launch_bounds__(kInflateStoredThreads) void inflate_stored_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
-                                                                                const uint32_t* __restrict__ in_len, uint32_t n,
-                                                                                uint8_t* __restrict__ out, uint64_t out_stride,
-                                                                                uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
-                                                                                uint32_t* __restrict__ work) {
-    __shared__ InflateStoredMem s_mem[kInflateStoredThreads / 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = blockIdx.x * (kInflateStoredThreads / 64) + wave;
-    if (chunk >= n) return;
-    const uint32_t nin = in_len[chunk];
-    InflateIo io{in + in_off[chunk], out + (size_t)chunk * out_stride, s_mem[wave].ring, (nin + 15u) & ~15u, lane, 0u};
-    InflateState st;
-    io.top_up(0);
-    uint32_t go = 0;
-    if (lane == 0) go = inflate_begin(st, io.ring, nin, kInfRing - 1u) ? 1u : 0u;
-    go = __builtin_amdgcn_readfirstlane(go);
-    while (go) {
-        uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
-        io.top_up(st.br.pos);
-        if (lane == 0) {
-            uint32_t type = 0;
-            opos = st.out_pos;
-            kind = inflate_block_type(st, type) ? inflate_block_rest(st, nullptr, nullptr, type, soff, slen) : (uint32_t)kBlkStop;
-        }
-        kind = __builtin_amdgcn_readfirstlane(kind);
-        if (kind == kBlkHuffman) { if (lane == 0) work[2u + atomicAdd(&work[0], 1u)] = chunk; return; }   // onto the second kernel's list
-        if (kind == kBlkStop) break;
-        soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen); opos = __builtin_amdgcn_readfirstlane(opos);
-        const uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
-        io.copy_stored(soff, opos, cp);
-        uint32_t stop = 0;
-        if (lane == 0) {
-            st.out_pos += cp;
-            if (cp < slen) st.status = kInfOverflow;
-            if (st.status == kInfRunning && st.last) st.status = kInfEnd;
-            stop = st.status != kInfRunning;
-        }
-        if (__builtin_amdgcn_readfirstlane(stop)) break;
-    }
-    if (lane == 0) { out_len[chunk] = st.out_pos; status[chunk] = st.status; }
-}
-
-// Second kernel: the chunks on the first one's list, whole.  One wave per workgroup, as many workgroups as the chip holds at
-// once; a wave takes the next listed chunk until the list is empty (every wave reaches the end: the list is final when this
-// kernel starts, the cursor only grows).  (One workgroup per chunk cost 0.5 ms on incompressible data, where 50 000 of
-// them started only to find nothing to do.)
-static __device__ __forceinline__ void inflate_one_chunk(InflateWaveMem& m, uint32_t chunk, uint32_t lane, const uint8_t* __restrict__ in,
-                                                         const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ in_len,
-                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
-                                                         uint32_t* __restrict__ status);
-
-__global__ __launch_bounds__(kInflateThreads) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
-                                                                  const uint32_t* __restrict__ in_len, uint32_t n,
-                                                                  uint8_t* __restrict__ out, uint64_t out_stride,
-                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
-                                                                  uint32_t* __restrict__ work) {
-    __shared__ InflateWaveMem s_mem;
-    static_assert(kInflateThreads == 64, "one wave per workgroup");
-    const uint32_t lane = lane_id();
-    const uint32_t listed = work[0];
-    for (;;) {
-        uint32_t idx = 0;
-        if (lane == 0) idx = atomicAdd(&work[1], 1u);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        if (idx >= listed) break;
-        const uint32_t chunk = work[2u + idx];
-        if (chunk < n) inflate_one_chunk(s_mem, chunk, lane, in, in_off, in_len, out, out_stride, out_len, status);
-    }
-}
-
-static __device__ __forceinline__ void inflate_one_chunk(InflateWaveMem& m, uint32_t chunk, uint32_t lane, const uint8_t* __restrict__ in,
-                                                         const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ in_len,
-                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
-                                                         uint32_t* __restrict__ status) {
-    uint8_t* dst = out + (size_t)chunk * out_stride;
-    const uint32_t nin = in_len[chunk];
-    InflateIo io{in + in_off[chunk], dst, m.ring, (nin + 15u) & ~15u, lane, 0u};
-    auto window = [&](uint32_t a) -> uint64_t {        // the stream from bit a on: >= 57 bits
-        const uint32_t byte = (a >> 3) & (kInfRing - 1u);
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
-        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
-        return (((uint64_t)hi << 32) | lo) >> (a & 7u);
     };
 
     InflateState st;
-    io.top_up(0);
+    top_up(0);
     uint32_t go = 0;
     if (lane == 0) go = inflate_begin(st, m.ring, nin, kInfRing - 1u) ? 1u : 0u;
     go = __builtin_amdgcn_readfirstlane(go);
+    uint32_t fenced = 0;      // every output byte below this offset is visible to the whole wave
     while (go) {
         uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
-        io.top_up(st.br.pos);
-        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, reinterpret_cast<uint8_t*>(m.own), soff, slen); }
+        top_up(st.br.pos);
+        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, m.lens, soff, slen); }
         kind = __builtin_amdgcn_readfirstlane(kind);
         if (kind == kBlkStop) break;
         if (kind == kBlkStored) {
             soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen);
             opos = __builtin_amdgcn_readfirstlane(opos);
-            const uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
-            io.copy_stored(soff, opos, cp);
+            uint32_t room = kChunk - opos, cp = slen < room ? slen : room;
+            // stored bytes: whole 16-byte vectors of output, each from five aligned input words shifted by the two
+            // ranges' relative misalignment (a 5-byte block header sits between them); bytes at the ragged ends singly.
+            // (One byte per lane per trip moved 1.7 TB/s with 5 k waves in flight; this is ~10x fewer instructions.)
+            {
+                const uint32_t head = min(cp, (16u - (opos & 15u)) & 15u);               // dst + opos + head is 16-byte aligned (dst is)
+                if (lane < head) dst[opos + lane] = src[soff + lane];
+                const uint32_t s0 = soff + head, d0 = opos + head, sh = s0 & 3u;
+                const uint32_t* sw = reinterpret_cast<const uint32_t*>(src + (s0 & ~3u));
+                uint32_t nvec = (cp - head) >> 4;
+                while (nvec && (s0 & ~3u) + 16u * nvec + 4u > nin16) nvec--;            // the fifth word must lie inside the readable extent
+                for (uint32_t v = lane; v < nvec; v += 64) {
+                    const uint32_t* q = sw + 4u * v;
+                    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                    *reinterpret_cast<uint4*>(dst + d0 + 16u * v) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                                                __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+                }
+                for (uint32_t i = head + 16u * nvec + lane; i < cp; i += 64) dst[opos + i] = src[soff + i];
+            }
             uint32_t stop = 0;
             if (lane == 0) {
                 st.out_pos += cp;
@@ -2017,139 +1820,220 @@ static __device__ __forceinline__ void inflate_one_chunk(InflateWaveMem& m, uint
             }
             if (__builtin_amdgcn_readfirstlane(stop)) break;
         } else {
+            // Huffman block.  Decoding is sequential only in where symbols START; what a symbol is,
+            // given its start bit, is a pure table lookup.  So every lane decodes the symbol that would
+            // start at each of its kWinSlots bit offsets of a 256-bit window (window bit o <-> lane o & 63,
+            // slot o >> 6), and a short scalar loop then hops through the true chain with v_readlane,
+            // dropping the symbols into the batch registers with v_writelane.  (Lane 0 decoding alone
+            // cost ~1900 cycles per symbol.)  Codes longer than the fast tables, and anything odd, fall
+            // back to the sequential decoder for one symbol, which also keeps zlib's exact error and
+            // truncation behaviour.
+            enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
             uint32_t bp = 0, opos_u = 0;
             if (lane == 0) { bp = st.br.bit_pos(); opos_u = st.out_pos; }
             bp = __builtin_amdgcn_readfirstlane(bp); opos_u = __builtin_amdgcn_readfirstlane(opos_u);
             const uint32_t total_bits = nin * 8u;
             uint32_t block_done = 0, stop_status = kInfRunning;
-            constexpr uint32_t kDead = 0xffffffffu;                       // "the stream does not get here this round"
             while (!block_done) {
-                io.top_up(bp >> 3);
-                // ---- 1. sync
-                const uint32_t bound = bp + kSubBits * (lane + 1u);
-                uint32_t start = bp + kSubBits * lane, endpos = 0, n_sym = 0, n_bytes = 0;
-                bool redo = true;
-                for (uint32_t pass = 0; pass < 64u; pass++) {
-                    {   // lanes whose start changed decode again; the loop body is predicated, not branched
-                        uint32_t pos = start == kDead ? bound : start, ns = 0, nby = 0;
-                        bool stopped = start == kDead;
-                        while (__builtin_amdgcn_ballot_w64(redo && !stopped && pos < bound)) {
-                            uint32_t nb, val;
-                            const uint32_t k = fast_decode(m.t, window(pos), (int32_t)(total_bits - pos), nb, val);
-                            const bool act = redo && !stopped && pos < bound;
-                            const bool plain = k <= kSyMatch;
-                            ns += (uint32_t)(act && plain);
-                            nby += act && plain ? (k == kSyLit ? 1u : val >> 16) : 0u;
-                            pos += act && plain ? nb : 0u;
-                            stopped = stopped || (act && !plain);
+                top_up(bp >> 3);
+                uint32_t inf[kWinSlots], val[kWinSlots];
+#pragma unroll
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    const uint32_t a = bp + r * 64u + lane;
+                    const int32_t avail = (int32_t)total_bits - (int32_t)a;
+                    const uint32_t byte = (a >> 3) & (kInfRing - 1u);
+                    const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
+                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);      // >= 57 valid bits
+                    uint32_t kind = kSlow, nb = 0, v = 0;
+                    const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
+                    const uint32_t l = e & 15u, s = e >> 4;
+                    if (e != 0) {
+                        if (s < 256u) { kind = kLit; nb = l; v = s; }
+                        else if (s == 256u) { kind = kEob; nb = l; }
+                        else {
+                            const uint32_t c = s - 257u;
+                            kind = kErr;
+                            if (c < 29u) {
+                                const uint32_t xb = length_extra_bits(c);
+                                const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
+                                const uint64_t rest = bits >> (l + xb);
+                                const uint32_t de = m.t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+                                const uint32_t dl = de & 15u, d = de >> 4;
+                                kind = kSlow;
+                                if (de != 0) {
+                                    kind = kErr;
+                                    if (d < 30u) {
+                                        const uint32_t dxb = dist_extra_bits(d);
+                                        const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
+                                        kind = kMatch; nb = l + xb + dl + dxb; v = (len << 16) | dist;
+                                    }
+                                }
+                            }
                         }
-                        if (redo) { endpos = stopped ? kDead : pos; n_sym = ns; n_bytes = nby; }
                     }
-                    uint32_t from_left = (uint32_t)__builtin_amdgcn_update_dpp((int)bp, (int)endpos, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps bp
-                    if (lane == 0) from_left = bp;
-                    redo = from_left != start;
-                    start = from_left;
-                    // Only the lanes up to the first one whose subsequence ends the round matter (an end of block, an
-                    // oddity, the payload's end): once THEIR starts agree with their left neighbours the sequence up to
-                    // that point is final, and what the lanes behind it hold is never looked at.  (Without this the "dead"
-                    // mark would walk to lane 63 one lane a pass at the end of every block.)
-                    const uint64_t enders = __builtin_amdgcn_ballot_w64(endpos == kDead);
-                    const uint64_t relevant = enders ? ((2ull << (uint32_t)__builtin_ctzll(enders)) - 1ull) : ~0ull;
-                    if ((__builtin_amdgcn_ballot_w64(redo) & relevant) == 0) {
-                        if (!((relevant >> lane) & 1ull)) { start = kDead; n_sym = 0; n_bytes = 0; }
-                        break;
-                    }
+                    if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
+                    inf[r] = kind | (nb << 3); val[r] = v;
                 }
-                // ---- 2. emit
-                for (uint32_t i = lane; i < kRoundBytes / 8u; i += 64u) reinterpret_cast<uint4*>(m.own)[i] = make_uint4(0, 0, 0, 0);
-                const uint32_t sidx = wave_scan_incl(n_sym) - n_sym, ooff = wave_scan_incl(n_bytes) - n_bytes;
+                // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
+                // A scalar loop hopping through it with v_readlane took ~50 SALU instructions a symbol, and a CU has ONE
+                // scalar issue slot a cycle for its 20 waves: 70 % of this kernel's time on text.  So the orbit is marked
+                // by pointer doubling over the 256 offsets (<= 8 rounds, usually 5), ranks and output positions come from
+                // ballots and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols,
+                // end of block, an error, a code for the sequential decoder) -- the same decisions in the same order
+                // of precedence as the loop they replace.
+                constexpr uint32_t kSink = 64u * kWinSlots;
+                uint32_t jr[kWinSlots];
+                uint8_t* flag8 = reinterpret_cast<uint8_t*>(m.flag);
+                m.flag[lane] = lane == 0 ? 1u : 0u;                       // offset 0 is reached by definition
+#pragma unroll
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    const uint32_t adv = r * 64u + lane + (inf[r] >> 3);
+                    jr[r] = (inf[r] & 7u) <= kMatch ? (adv < kSink ? adv : kSink) : kSink;      // only literals and matches lead on
+                    m.jump[r * 64u + lane] = (uint16_t)jr[r];
+                }
+                if (lane == 0) m.jump[kSink] = (uint16_t)kSink;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t e_kind = kSyNone, e_pos = start == kDead ? bound : start, e_nb = 0, e_syms = 0, e_bytes = 0;
-                {
-                    bool stopped = start == kDead;
-                    while (__builtin_amdgcn_ballot_w64(!stopped && e_pos < bound)) {
-                        uint32_t nb, val;
-                        uint32_t k = fast_decode(m.t, window(e_pos), (int32_t)(total_bits - e_pos), nb, val);
-                        const bool act = !stopped && e_pos < bound;
-                        const uint32_t p = opos_u + ooff + e_bytes, si = sidx + e_syms;
-                        const uint32_t blen = k == kSyLit ? 1u : val >> 16;
-                        // what the symbol's place in the output decides: too far back, past the 65535-byte cap, round full
-                        k = k == kSyMatch && (val & 0xffffu) > p ? kSyData : k;
-                        k = k <= kSyMatch && p + blen > kChunk ? kSyOverflow : k;
-                        k = k <= kSyMatch && (si >= kRoundSyms || p + blen - opos_u > kRoundBytes) ? kSyCut : k;   // the next round starts here
-                        const bool plain = act && k <= kSyMatch;
-                        if (plain) {
-                            m.sym[si] = make_uint2(val, p);
-                            m.own[p - opos_u] = (uint16_t)(si + 1u);
+                uint64_t M[kWinSlots] = {1ull, 0ull, 0ull, 0ull};           // reached offsets, slot by slot (wave-uniform)
+                for (uint32_t round = 0; round < 8; round++) {
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++)                 // everything reached so far marks what lies 2^round symbols on
+                        if (((M[r] >> lane) & 1ull) && jr[r] < kSink) flag8[jr[r]] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    bool grown = false;
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) {
+                        const uint64_t now = __ballot(flag8[r * 64u + lane] != 0);
+                        grown = grown || now != M[r];
+                        M[r] = now;
+                    }
+                    if (!grown) break;
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) jr[r] = m.jump[jr[r]];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                    for (uint32_t r = 0; r < kWinSlots; r++) m.jump[r * 64u + lane] = (uint16_t)jr[r];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                // Ranks (symbol index in the batch) and output positions of the reached offsets, in window order; the first
+                // reached offset at which the batch must end decides how the round ends.  Symbols go into the batch arrays
+                // as they are ranked; the entries from the end of the batch on are blanked afterwards.
+                m.pos[lane] = 0xffffffffu;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t base = 0, carry = 0, cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
+                bool ended = false;
+#pragma unroll
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow,
+                    // ~100 scalar instructions per slot -- and the scalar unit is what this kernel runs out of)
+                    const uint32_t kd = inf[r] & 7u;
+                    const uint32_t mk = (uint32_t)(M[r] >> lane) & 1u;
+                    const uint32_t rank = base + rank_in(M[r]);
+                    const uint32_t is_lit = (uint32_t)(kd == kLit), is_match = (uint32_t)(kd == kMatch), mlen = val[r] >> 16;
+                    const uint32_t ol = mk * (is_lit + is_match * mlen);
+                    const uint32_t sc = wave_scan_incl(ol);
+                    const uint32_t pos = opos_u + carry + sc - ol;
+                    const uint32_t ends = mk & ((uint32_t)(rank >= kBatch) | (uint32_t)(kd >= kEob) | (is_lit & (uint32_t)(pos >= kChunk)) |
+                                                (is_match & ((uint32_t)((val[r] & 0xffffu) > pos) | (uint32_t)(pos + mlen > kChunk))));
+                    if (mk & (ends ^ 1u)) { m.batch[rank] = val[r]; m.pos[rank] = pos; }      // not at an end implies rank < kBatch
+                    const uint64_t C = __ballot(ends != 0);
+                    if (!ended && C) {                                     // wave-uniform: the round ends at this offset
+                        ended = true;
+                        const uint32_t lc = (uint32_t)__builtin_ctzll(C);
+                        const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_rank = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)lc);
+                        const uint32_t c_val = (uint32_t)__builtin_amdgcn_readlane((int)val[r], (int)lc);
+                        opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
+                        cur = r * 64u + lc;
+                        k = c_rank < kBatch ? c_rank : kBatch;
+                        if (c_rank >= kBatch) { /* batch full: the next round starts at this symbol */ }
+                        else if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
+                        else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
+                        else if (c_kind == kEob) { cur += (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)lc); stop = kEob; }
+                        else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
+                    }
+                    if (!ended && M[r]) {                                  // so far plain symbols: the chain leaves the window behind the last of them
+                        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(M[r]);
+                        cur = r * 64u + ll + (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)ll);
+                    }
+                    base += (uint32_t)__popcll(M[r]);
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                }
+                if (!ended) { k = base; opos_new = opos_u + carry; }
+                bp += cur;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane >= k) m.pos[lane] = 0xffffffffu;                  // symbols ranked behind the end of the batch do not belong to it
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // The wave moves the bytes of this batch, one output byte per lane per trip: find the
+                // symbol that produces the byte (binary search over the batch's start offsets), follow
+                // back-references that point into this same batch until they land on a literal of the
+                // batch or on output of an earlier batch, then load/store.  All loads of a trip are in
+                // flight together (copying match by match cost one L2 round trip per match: ~9 ms a chunk).
+                // The batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
+                // owners here; indexed LDS reads are also cheaper than eight bpermutes).
+                const uint32_t bstart = opos_u;
+                const uint32_t bbytes = opos_new - bstart;
+                opos_u = opos_new;
+                auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t stp = 32; stp >= 1; stp >>= 1) { const uint32_t q = m.pos[(lo + stp) & 63u]; if (q <= pos) lo += stp; }
+                    ov = m.batch[lo]; op = m.pos[lo];
+                };
+                bool need_fence = false;
+                for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
+                    const uint32_t pos = bstart + j0 + lane;
+                    const bool in = j0 + lane < bbytes;
+                    uint32_t ov = 0, op = 0;
+                    owner(in ? pos : bstart, ov, op);
+                    uint32_t src = 0; bool lit = ov < 256u;
+                    if (!lit) { const uint32_t d = ov & 0xffffu; src = op - d + ((pos - op) % d); }
+                    // chase references into this batch (wave-uniform loop, lanes drop out as they resolve)
+                    while (__ballot(in && !lit && src >= bstart)) {
+                        const bool go2 = in && !lit && src >= bstart;
+                        uint32_t ov2 = 0, op2 = 0;
+                        owner(go2 ? src : bstart, ov2, op2);
+                        if (go2) {
+                            if (ov2 < 256u) { lit = true; ov = ov2; }
+                            else { const uint32_t d = ov2 & 0xffffu; src = op2 - d + ((src - op2) % d); }
                         }
-                        e_syms += (uint32_t)plain; e_bytes += plain ? blen : 0u; e_pos += plain ? nb : 0u;
-                        if (act && !plain) { e_kind = k; e_nb = nb; }
-                        stopped = stopped || (act && !plain);
                     }
+                    const uint64_t far = __ballot(in && !lit && src + 1u > fenced);
+                    if (far) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = bstart; }
+                    // back-references read bytes this CU stored a moment ago: agent-scope (sc1) loads are served
+                    // by L2 and cannot hit a stale L1 line that was cached before the store
+                    if (in) dst[pos] = lit ? (uint8_t)ov : __hip_atomic_load(&dst[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)need_fence;
                 }
-                // the round ends at the first lane, in stream order, that met something other than a plain symbol
-                const uint64_t enders = __builtin_amdgcn_ballot_w64(e_kind != kSyNone);
-                const uint32_t el = enders ? (uint32_t)__builtin_ctzll(enders) : 63u;
-                uint32_t r_kind = enders ? (uint32_t)__builtin_amdgcn_readlane((int)e_kind, (int)el) : kSyNone;
-                const uint32_t r_pos = (uint32_t)__builtin_amdgcn_readlane((int)e_pos, (int)el);
-                uint32_t r_nb = (uint32_t)__builtin_amdgcn_readlane((int)e_nb, (int)el);
-                const uint32_t nbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + e_bytes), (int)el);
-                // (with no ender lane 63 is a live lane that ran to the end of its subsequence: r_pos is where the next round starts)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // ---- 3. copy
-                // every store of earlier rounds (and blocks) has to be in L2 before a back-reference reads it
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
-                const uint32_t trips = (nbytes + 63u) >> 6;
-                {   // the symbol that owns each byte: latest start at or before it
-                    uint32_t carry = 0;
-                    for (uint32_t tr = 0; tr < trips; tr++) {
-                        const uint32_t v = m.own[tr * 64u + lane];
-                        const uint32_t o = max(wave_scan_max_incl(v), carry);
-                        m.own[tr * 64u + lane] = (uint16_t)o;
-                        carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+                if (stop == kEob) block_done = 1;
+                else if (stop == kSlow) {
+                    // one symbol through the sequential decoder (long code, or its exact failure mode)
+                    uint32_t k1 = 0, d1 = 0, nbp = bp, nop = opos_u, stt = kInfRunning;
+                    if (lane == 0) {
+                        st.br.seek_bit(bp); st.out_pos = opos_u;
+                        bool d;
+                        k1 = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d, 1u);
+                        d1 = d; nbp = st.br.bit_pos(); nop = st.out_pos; stt = st.status;
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                for (uint32_t tr = 0; tr < trips; tr++) {
-                    const uint32_t j = opos_u + tr * 64u + lane;
-                    const bool inr = tr * 64u + lane < nbytes;
-                    uint2 sy = m.sym[inr ? (uint32_t)m.own[tr * 64u + lane] - 1u : 0u];
-                    bool lit = sy.x < 256u;
-                    uint32_t from = match_source(j, sy.y, sy.x & 0xffffu, inr && !lit);
-                    // references into this round: through LDS, symbol by symbol, until a literal or older output
-                    while (__builtin_amdgcn_ballot_w64(inr && !lit && from >= opos_u)) {
-                        const bool hop = inr && !lit && from >= opos_u;
-                        const uint2 s2 = m.sym[hop ? (uint32_t)m.own[from - opos_u] - 1u : 0u];
-                        const uint32_t f2 = match_source(from, s2.y, s2.x & 0xffffu, hop && s2.x >= 256u);
-                        if (hop) { sy = s2; lit = s2.x < 256u; from = lit ? from : f2; }
+                    k1 = __builtin_amdgcn_readfirstlane(k1); d1 = __builtin_amdgcn_readfirstlane(d1);
+                    bp = __builtin_amdgcn_readfirstlane(nbp); opos_u = __builtin_amdgcn_readfirstlane(nop);
+                    stt = __builtin_amdgcn_readfirstlane(stt);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (k1) {
+                        const uint32_t mv = m.batch[0], mp = m.pos[0];
+                        if (mv < 256u) { if (lane == 0) dst[mp] = (uint8_t)mv; }
+                        else {
+                            const uint32_t len = mv >> 16, dist = mv & 0xffffu;
+                            const uint32_t from = mp - dist, span = len < dist ? len : dist;
+                            if (from + span > fenced) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                                __builtin_amdgcn_s_waitcnt(0);
+                                fenced = mp;
+                            }
+                            for (uint32_t i = lane; i < len; i += 64) dst[mp + i] = __hip_atomic_load(&dst[from + (i % dist)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
-                    // older output was stored by this CU a moment ago: agent-scope (sc1) loads are served by L2 and
-                    // cannot hit a stale L1 line that was cached before the store
-                    if (inr) dst[j] = lit ? (uint8_t)sy.x : __hip_atomic_load(&dst[from], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                opos_u += nbytes;
-                bp = r_pos;
-                if (r_kind == kSySlow) {
-                    // the fast tables could not settle this symbol: every lane decodes it with the full rules (wave-uniform)
-                    uint32_t val;
-                    r_kind = careful_decode(m.t, window(bp), (int32_t)(total_bits - bp), r_nb, val);
-                    if (r_kind == kSyMatch && (val & 0xffffu) > opos_u) r_kind = kSyData;
-                    else if (r_kind <= kSyMatch && opos_u + (r_kind == kSyLit ? 1u : val >> 16) > kChunk) r_kind = kSyOverflow;
-                    if (r_kind == kSyLit) { if (lane == 0) dst[opos_u] = (uint8_t)val; opos_u += 1u; bp += r_nb; }
-                    else if (r_kind == kSyMatch) {
-                        const uint32_t len = val >> 16, dist = val & 0xffffu, from = opos_u - dist;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this round's stores first
-                        __builtin_amdgcn_s_waitcnt(0);
-                        for (uint32_t i = lane; i < len; i += 64) dst[opos_u + i] = __hip_atomic_load(&dst[from + (i % dist)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        opos_u += len; bp += r_nb;
-                    }
-                }
-                if (r_kind == kSyEob) { bp += r_nb; block_done = 1; }
-                else if (r_kind == kSyNeed) { stop_status = kInfNeedInput; block_done = 1; }
-                else if (r_kind == kSyData) { stop_status = kInfDataError; block_done = 1; }
-                else if (r_kind == kSyOverflow) { stop_status = kInfOverflow; block_done = 1; }
-                // kSyLit / kSyMatch (settled above) / kSyCut / kSyNone: the next round starts at bp
+                    if (d1) { block_done = 1; stop_status = stt; }
+                } else if (stop != 0xffu) { block_done = 1; }          // need / error / overflow: status already set
             }
             // hand the position back to lane 0's reader for the next block header
             uint32_t halt = 0;
@@ -2354,14 +2238,9 @@ hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uin
 
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    // stored-only chunks in a kernel of their own (ring only: 20 waves a CU); what it leaves (kInfPending) to the full decoder
-    const uint32_t per_s = kInflateStoredThreads / 64;
-    ZWZ_TRY(hipMemsetAsync(a.work, 0, 2 * sizeof(uint32_t), s));          // list length, cursor
-    hipLaunchKernelGGL(inflate_stored_kernel, dim3((a.n + per_s - 1) / per_s), dim3(kInflateStoredThreads), 0, s, a.in, a.in_off, a.in_len, a.n,
-                       a.out, a.out_stride, a.out_len, a.status, a.work);
-    const uint32_t resident = a.resident_waves ? a.resident_waves : 2304u;
-    hipLaunchKernelGGL(inflate_kernel, dim3(a.n < resident ? a.n : resident), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
-                       a.out_stride, a.out_len, a.status, a.work);
+    const uint32_t per = kInflateThreads / 64;
+    hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
+                       a.out_stride, a.out_len, a.status);
     return hipGetLastError();
 }
 
