@@ -13,15 +13,12 @@ constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
 constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
 constexpr uint32_t kLinksThreads = 576;                            // one inserter wave + eight feeder waves per chunk
 constexpr uint32_t kLinksLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // 32-bit head table + spare slot + two bucket-address/link buffers + slack for read-ahead
-constexpr uint32_t kTile = 4096, kTilesPerChunk = 16;
+constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
-constexpr uint32_t kMatchWinData = 36896;                       // data bytes the window holds: [tile - 32506 (rounded down to 16), tile + 4096 + 266)
-constexpr uint32_t kMatchDataBytes = 16 + 2 * kMatchWinData;    // the "D8" window: two LDS bytes per data byte (zwz_kernels.hip), 16 bytes of guard in front
-constexpr uint32_t kMatchLinkBytes = 2 * 36624;                 // links [tile - 32506 (rounded down), tile + 4096)
-constexpr uint32_t kMatchHasBytes = kTile / 8;                  // has128 bits of a tile
-constexpr uint32_t kMatchListBytes = 14336;                     // key counts of a sorted tile (2 KB) / per-wave work lists of a sparse tile
-constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + kMatchHasBytes + kMatchListBytes;   // 161904 of 163840 (with 64 static)
-static_assert(kMatchLdsBytes + 64 <= 163840 && kMatchDataBytes % 16 == 0 && kMatchLinkBytes % 16 == 0, "lz_match's LDS budget");
+constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
+constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
+constexpr uint32_t kMatchListBytes = 4096 + 10240;               // bucket counts of a sorted tile / per-wave work lists of a sparse tile
+constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163520 of 163840 (with 64 static)
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
                 :
                 : [base] "v"(base), [p0] "v"(p0)
                 : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-                  "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v90", "v91", "v126");
+                  "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
             s = n_steps;
         } else if (n_steps >= 6u) {
             // steps s, s+1 issued; bucket addresses of s+2, s+3 at hand; then three steps a trip: read the address of step t+2,
@@ -455,31 +455,6 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
     for (; i < n; i += T) dst[i] = src[i];
 }
 
-// The data window of lz_match in LDS ("D8"): every 4-byte-aligned offset of the window owns an 8-byte word holding the
-// bytes [4k, 4k + 8) -- each dword is stored twice, as the low half of its own word and the high half of the one before.
-// Any 4 bytes at any byte offset then sit inside ONE naturally aligned 8-byte word: one ds_read_b64, which under random
-// addresses costs the LDS what one ds_read_b32 does (64 banks for 32 lanes of 8 bytes against 32 banks for 32 lanes of 4),
-// where the plain byte array needed two dword gathers.  The chain walk is bound by exactly those gathers.
-// Byte x of the window lives at d8[2 * (x & ~3) + (x & 3)].
-static __device__ __forceinline__ uint32_t d8_u32(const uint8_t* d8, uint32_t x) {          // 4 bytes at any byte offset
-    const uint2 w = *reinterpret_cast<const uint2*>(d8 + 2u * (x & ~3u));
-    return __builtin_amdgcn_alignbyte(w.y, w.x, x & 3u);
-}
-static __device__ __forceinline__ uint32_t d8_byte(const uint8_t* d8, uint32_t x) { return d8[2u * x - (x & 3u)]; }
-static __device__ __forceinline__ uint2 d8_pair(const uint8_t* d8, uint32_t x4) {          // bytes [x4, x4 + 8), x4 a multiple of 4
-    return *reinterpret_cast<const uint2*>(d8 + 2u * x4);
-}
-// lz_core.h's match_len_from on the D8 window
-static __device__ __forceinline__ uint32_t d8_match_len_from(const uint8_t* d8, uint32_t a, uint32_t b, uint32_t k0, uint32_t max_len) {
-    uint32_t k = k0;
-    while (k < max_len) {
-        const uint32_t x = d8_u32(d8, a + k) ^ d8_u32(d8, b + k);
-        if (x) { k += (uint32_t)__builtin_ctz(x) >> 3; break; }
-        k += 4;
-    }
-    return k < max_len ? k : max_len;
-}
-
 // lz_core.h's lz_search, restated for a whole wave: same candidates, same order, same records.
 // The chain walk is the framework's hottest loop.  Written per lane it compiles to ~32 instructions
 // per candidate, a third of them exec-mask bookkeeping for the per-lane exits; a predicated C++
@@ -489,10 +464,10 @@ static __device__ __forceinline__ uint32_t d8_match_len_from(const uint8_t* d8, 
 // wave-uniform (an SGPR), `alive` is an SGPR lane mask, a lane whose chain has ended keeps
 // re-reading its last candidate, and the loop falls out to C++ only when some live lane's filter
 // word matches (worth a full comparison), the counter reaches its bound, or no lane is left.
-// A candidate costs two LDS gathers: the 8-byte word of the D8 window that holds its filter bytes, and its link.
-// (One unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time;
-// two aligned dword reads and an alignbyte, the round-1 form, made it three gathers a candidate.)
-static __device__ __forceinline__ void lz_search_wave(const uint8_t* data /* D8 window */, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
+// (The filter word is two adjacent aligned dwords -- ONE ds_read2_b32 into a named register pair, which costs the LDS
+// ~13 cycles under random addresses against 2 x 10 for two ds_read_b32 (tools/exp/gather_rate.hip) -- and an alignbyte:
+// one unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.)
+static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
                                                       bool active, uint32_t& e128, uint32_t& e32) {
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
     e128 = 0; e32 = 0;
@@ -512,31 +487,28 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data /* D8 
     constexpr uint32_t kNone = 0xffffffffu;
     uint32_t best = kMinMatch - 1, best_pos = 0, snap = kNone;
     uint32_t f_off = 0, f_mask = 0xffffffu;                        // see lz_search: the filter word
-    const uint2 scan01 = d8_pair(data, pp & ~3u);
-    const uint32_t scan2 = d8_pair(data, (pp & ~3u) + 8u).x;
-    const uint32_t scan0 = __builtin_amdgcn_alignbyte(scan01.y, scan01.x, pp & 3u), scan1 = __builtin_amdgcn_alignbyte(scan2, scan01.y, pp & 3u);   // the scan's
-    uint32_t scan_w = scan0 & f_mask;                                             // first eight bytes: most full comparisons end inside them
-    const uint32_t data_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)const_cast<uint8_t*>(data));                          // LDS byte addresses
+    const uint32_t scan0 = load_u32(data, pp), scan1 = load_u32(data, pp + 4u);   // the scan's first eight bytes: most full
+    uint32_t scan_w = scan0 & f_mask;                                             // comparisons end inside them, without a loop
+    const uint32_t data_a = (uint32_t)(uintptr_t)(lds_ptr)const_cast<uint8_t*>(data);                          // LDS byte addresses
     const uint32_t link_a = (uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(link));
     const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a - 2u * org);
-    uint32_t xbias = f_off - org;                                  // filter bytes of candidate c: window bytes cur + xbias ...
+    uint32_t dbias = data_a - org + f_off;                         // filter word of candidate c: LDS byte cur + dbias
     uint32_t n = 0;                                                // candidates examined: the same in every lane
     // (a macro, not a lambda: with the SGPR operands captured by reference the backend fails with
     // "illegal VGPR to SGPR copy")
 #define ZWZ_WALK(BOUND_)                                                                           \
         for (;;) {                                                                                  \
-            uint64_t hit; uint32_t next, ta, tb, w0, tl;                                            \
+            uint64_t hit; uint32_t next, ta, tb, w0, tl;                                        \
             asm volatile(                                                                           \
                 "1:\n\t"                                                                            \
-                "v_add_u32 %[a], %[cur], %[xbias]\n\t"                                              \
+                "v_add_u32 %[a], %[cur], %[dbias]\n\t"                                              \
                 "v_and_b32 %[b], -4, %[a]\n\t"                                                      \
-                "v_lshl_add_u32 %[b], %[b], 1, %[d8]\n\t"                                           \
-                "ds_read_b64 v[90:91], %[b]\n\t"                                                  \
+                "ds_read2_b32 v[90:91], %[b] offset1:1\n\t"                                         \
                 "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"                                      \
                 "ds_read_u16 %[next], %[l]\n\t"                                                     \
                 "v_and_b32 %[a], 3, %[a]\n\t"                                                       \
                 "s_waitcnt lgkmcnt(1)\n\t"                                                          \
-                "v_alignbyte_b32 %[w0], v91, v90, %[a]\n\t"                                       \
+                "v_alignbyte_b32 %[w0], v91, v90, %[a]\n\t"                                         \
                 "v_and_b32 %[w0], %[w0], %[fmask]\n\t"                                              \
                 "v_cmp_eq_u32 vcc, %[w0], %[scan]\n\t"                                              \
                 "s_and_b64 %[hit], vcc, %[alive]\n\t"                                               \
@@ -553,23 +525,21 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data /* D8 
                 "s_waitcnt lgkmcnt(0)"                                                              \
                 : [cur] "+v"(cur), [alive] "+s"(alive), [n] "+s"(n), [hit] "=&s"(hit), [next] "=&v"(next), [a] "=&v"(ta), [b] "=&v"(tb),\
                   [w0] "=&v"(w0), [l] "=&v"(tl)                                                     \
-                : [xbias] "v"(xbias), [d8] "s"(data_a), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(BOUND_)\
-                : "vcc", "scc", "memory", "v90", "v91");                                          \
+                : [dbias] "v"(dbias), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(BOUND_)\
+                : "vcc", "scc", "memory", "v90", "v91");                                            \
             if (hit == 0) break;                                                                    \
             if ((hit >> lane) & 1ull) {                                                             \
                 const uint32_t c_ = cur - org;                                                      \
-                const uint2 c01 = d8_pair(data, c_ & ~3u);                                          \
-                const uint32_t c2 = d8_pair(data, (c_ & ~3u) + 8u).x;                               \
-                uint32_t x0 = __builtin_amdgcn_alignbyte(c01.y, c01.x, c_ & 3u) ^ scan0, x1 = __builtin_amdgcn_alignbyte(c2, c01.y, c_ & 3u) ^ scan1;\
+                uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;    \
                 asm volatile("" : "+v"(x0), "+v"(x1));   /* both words now: left alone, the second read is sunk behind a branch on the first */\
                 const uint32_t l0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, l1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3);\
                 uint32_t len = x0 ? l0 : x1 ? l1 : 8u;                                              \
-                if (len == 8u) len = d8_match_len_from(data, c_, pp, 8u, max_len);                  \
+                if (len == 8u) len = match_len_from(data, c_, pp, 8u, max_len);                     \
                 len = len < max_len ? len : max_len;                                                \
                 if (len > best) {                                                                   \
                     best = len; best_pos = cur;                                                     \
                     if (len >= nice) next = 0;                                                      \
-                    else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = d8_u32(data, pp + f_off); xbias = f_off - org; }\
+                    else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a - org + f_off; }\
                 }                                                                                   \
             }                                                                                       \
             n++;                                                                                    \
@@ -591,14 +561,12 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data /* D8 
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz_match: per-position match records.  One workgroup walks one chunk tile by tile (4 Ki positions
+// lz_match: per-position match records.  One workgroup walks one chunk tile by tile (16 Ki positions
 // per tile) with the history zlib may look at -- bytes and links of the last 32506 positions --
-// resident in LDS: the bytes as the D8 window above (two LDS bytes per data byte), the links as 16-bit positions.
-// Between tiles the window is slid inside LDS and only the next tile's own 4 KiB of bytes + 8 KiB of links
-// come from HBM, fetched into registers while the current tile is being searched (a tile-per-workgroup
-// version re-read the whole window per tile and spent 58% of its wave-cycles waiting on it).
-// (Round 1: a plain byte window and 16 Ki-position tiles in the same 147 KB; the walk then paid three LDS gathers a
-// candidate -- two dwords for the unaligned filter word, one link -- and the kernel's time on text was those gathers.)
+// resident in LDS.  Between tiles the window is slid inside LDS and only the next tile's own
+// 16 KiB of bytes + 32 KiB of links come from HBM, fetched into registers while the current tile
+// is being searched (a tile-per-workgroup version re-read the whole 147 KB window per tile and
+// spent 58% of its wave-cycles waiting on it).
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128,
@@ -607,14 +575,13 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
     if (L == 0) return;
-    uint8_t* sd8 = smem + 16;                                          // D8 window (the 16 bytes in front take word -1's high half)
+    uint8_t* sdata = smem;
     uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
-    uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // has128 bits of a tile
-    uint16_t* s_cnt = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes + kMatchLinkBytes + kMatchHasBytes);   // key counts / work lists
+    uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // 2 KiB: has128 bits of a tile
+    uint16_t* s_cnt = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes + kMatchLinkBytes + 2048);   // 4 KiB: bucket counts
     __shared__ uint32_t s_wtot[kMatchThreads / 64];
     uint16_t* perm = perms + (size_t)chunk * kTile;
-    uint32_t* sw32 = reinterpret_cast<uint32_t*>(sd8);
-    uint4* sd4 = reinterpret_cast<uint4*>(sd8);
+    uint4* sd4 = reinterpret_cast<uint4*>(sdata);
     uint4* sl4 = reinterpret_cast<uint4*>(slink);
     const uint4* gd4 = reinterpret_cast<const uint4*>(in + in_off[chunk]);                    // 16-byte aligned (API contract)
     const uint4* gl4 = reinterpret_cast<const uint4*>(links + (size_t)chunk * kLinkStride);
@@ -623,51 +590,48 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     const uint32_t ntiles = (L + kTile - 1) / kTile;
     const uint32_t dvec_total = (L + 15u) >> 4;     // the slot is readable to L rounded up to 16; bytes past L
                                                     // never influence a result (compares are capped at the lookahead)
-    // vectors [dlo, dhi) of data and [llo, lhi) of links are what tile t adds to the window (at most 273 / 512: one a thread)
+    // vectors [dlo, dhi) of data and [llo, lhi) of links are what tile t adds to the window
 #define ZWZ_TILE_RANGE(t)                                                                          \
     const uint32_t te_ = min(((t) + 1) * kTile, L), pe_ = (t) ? min((t) * kTile, L) : 0u;          \
     const uint32_t dlo = (t) ? min((pe_ + kMaxMatch + 8u + 15u) >> 4, dvec_total) : 0u;            \
     const uint32_t dhi = min((te_ + kMaxMatch + 8u + 15u) >> 4, dvec_total);                       \
     const uint32_t llo = (pe_ + 7u) >> 3, lhi = (te_ + 7u) >> 3;
-    static_assert(kTile / 16 + (kMaxMatch + 8 + 15) / 16 + 1 <= kMatchThreads && kTile / 8 <= kMatchThreads, "one vector a thread per tile");
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    uint4 pd0 = z4, pl0 = z4;                       // next tile's bytes / links in flight
+    uint4 pd0 = z4, pd1 = z4, pl0 = z4, pl1 = z4;   // next tile's bytes / links in flight
 #define ZWZ_PREFETCH(t)                                                                            \
     {                                                                                              \
         ZWZ_TILE_RANGE(t)                                                                          \
         if (dlo + tid < dhi) pd0 = gd4[dlo + tid];                                                 \
+        if (dlo + tid + kMatchThreads < dhi) pd1 = gd4[dlo + tid + kMatchThreads];                 \
         if (llo + tid < lhi) pl0 = gl4[llo + tid];                                                 \
+        if (llo + tid + kMatchThreads < lhi) pl1 = gl4[llo + tid + kMatchThreads];                 \
     }
     // chain-heavy data (four of five positions have a chain predecessor: text) takes the sorted work order, sparse
     // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
     const bool sorted_order = link_stat[chunk] * 5u >= L * 4u;      // workgroup-uniform
-    for (uint32_t i = tid; i < kMatchHasBytes / 4u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
+    for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
     uint32_t org = 0;
     ZWZ_PREFETCH(0u)
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint32_t ts = t * kTile, te = min(ts + kTile, L);
-        {   // registers -> LDS window whose first byte is position org.  A data dword goes in twice: low half of its own
-            // word, high half of the word before (two adjacent LDS dwords)
+        {   // registers -> LDS window whose first byte is position org
             ZWZ_TILE_RANGE(t)
-            if (dlo + tid < dhi) {
-                const uint32_t j0 = 4u * (dlo + tid - (org >> 4));          // window dword index of the vector's first dword
-                const uint32_t d[4] = {pd0.x, pd0.y, pd0.z, pd0.w};
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) { sw32[2u * (j0 + i) - 1u] = d[i]; sw32[2u * (j0 + i)] = d[i]; }
-            }
+            if (dlo + tid < dhi) sd4[dlo + tid - (org >> 4)] = pd0;
+            if (dlo + tid + kMatchThreads < dhi) sd4[dlo + tid + kMatchThreads - (org >> 4)] = pd1;
             if (llo + tid < lhi) sl4[llo + tid - (org >> 3)] = pl0;
+            if (llo + tid + kMatchThreads < lhi) sl4[llo + tid + kMatchThreads - (org >> 3)] = pl1;
         }
         __syncthreads();
         if (t + 1 < ntiles) ZWZ_PREFETCH(t + 1)     // in flight during the search below
 
         // Order of work inside the tile.  A wave finishes a trip when its longest chain does, and chain
         // lengths run from 1 to 128 among neighbouring positions (21-29% VALU lane utilisation on
-        // text in natural order).  Chain-heavy chunks sort the tile by a prediction of the chain length (below);
-        // chunks with sparse chains (lz_links' count, above) take the screening pass instead.
+        // text).  Positions with a similar distance to their second predecessor have similar chain
+        // lengths, so the tile is counting-sorted by an 8-bucket key of that distance and waves take 64
+        // positions of one bucket at a time (~0.58 utilisation, half the trips).  Chunks with sparse
+        // chains (lz_links' count, above) take the screening pass instead.
         const uint32_t npos = te - ts;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = lane_id();   // (the compiler does not see tid >> 6 as wave-uniform)
-        constexpr uint32_t kPer = kTile / kMatchThreads;           // positions a thread per tile: 4
-        static_assert(kPer == 4, "the sorted order below takes a thread's four positions as one group");
         uint32_t nlist = npos;                                     // sorted order: positions on the work list (wave-uniform after the scan)
         if (sorted_order) {
             // The key is a prediction of how many candidates the walk will visit: the chain is followed for up to kKeyDepth
@@ -676,15 +640,14 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             // quantised to 15 half-octave buckets.  A position whose first candidate is out of play (the test
             // lz_search_wave starts with) has no record and is left off the list altogether: key 0.
             // (Offline, on the text corpus: the second-predecessor key of round 1 gave 0.62 lane utilisation in the
-            // walk, this one 0.84, the true chain length 0.99; tools/exp/chain_keys.py.  The kernel's time moved less
-            // than that: a gather's cost in the LDS grows with the lanes that take part in it.)
+            // walk, this one 0.84, the true chain length 0.99; tools/exp/chain_keys.py.)
             constexpr uint32_t kKeyDepth = 8;
-            uint32_t key[kPer];
-            {   // positions ts + tid + j * kMatchThreads: four chains in flight
-                uint32_t p[kPer], cur[kPer], cnt[kPer], lim[kPer], live[kPer];
+            uint64_t mykeys = 0, myrank_lo = 0, myrank_hi = 0;            // 16 positions a thread: 4-bit keys, 8-bit ranks
+            auto keys_of4 = [&](uint32_t q0, uint32_t key[4]) {       // positions ts + q0 + j * kMatchThreads: four chains in flight
+                uint32_t p[4], cur[4], cnt[4], lim[4], live[4];
 #pragma unroll
-                for (uint32_t j = 0; j < kPer; j++) {
-                    p[j] = ts + tid + j * kMatchThreads;
+                for (uint32_t j = 0; j < 4; j++) {
+                    p[j] = ts + q0 + j * kMatchThreads;
                     const bool ok = p[j] < te && p[j] + kMinMatch <= L;
                     const uint32_t l1 = slink[ok ? p[j] - org : 0u];
                     live[j] = (uint32_t)(ok && l1 != 0 && p[j] - l1 <= kMaxDist && !(p[j] >= kSlidePos && l1 <= kWSize));
@@ -695,14 +658,14 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 #pragma unroll
                 for (uint32_t st = 1; st < kKeyDepth; st++) {
 #pragma unroll
-                    for (uint32_t j = 0; j < kPer; j++) {
+                    for (uint32_t j = 0; j < 4; j++) {
                         const uint32_t nx = slink[cur[j] - org];
                         const uint32_t adv = live[j] & (uint32_t)(nx > lim[j]);
                         cur[j] = adv ? nx : cur[j]; cnt[j] += adv; live[j] = adv;
                     }
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < kPer; j++) {
+                for (uint32_t j = 0; j < 4; j++) {
                     float est = (float)cnt[j];
                     if (cnt[j] == kKeyDepth) {
                         const uint32_t win = p[j] < kMaxDist ? p[j] : kMaxDist;
@@ -712,52 +675,72 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     const uint32_t k = 1u + (uint32_t)(__log2f(fmaxf(est, 1.0f)) * 2.0f);
                     key[j] = cnt[j] ? (k > 15u ? 15u : k) : 0u;
                 }
-            }
+            };
             // One-hot byte per key in four dwords, add-scanned over the wave: a lane's own field of the scan is its rank among
             // the wave's lanes with that key, lane 63's fields are the wave's counts (<= 64: a byte holds them).
-            // counts[key][group][wave] -> exclusive scan -> destination of every listed position
-            uint32_t myrank = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < kPer; j++) {
-                const uint32_t one = key[j] ? 1u << (8u * (key[j] & 3u)) : 0u, word = key[j] >> 2;
+            auto wave_key_rank = [&](uint32_t key, uint32_t& rank, uint32_t& count_for_lane) {
+                const uint32_t one = key ? 1u << (8u * (key & 3u)) : 0u, word = key >> 2;
                 uint32_t inc[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) inc[i] = wave_scan_incl(word == i ? one : 0u);
                 const uint32_t mine = word == 0 ? inc[0] : word == 1 ? inc[1] : word == 2 ? inc[2] : inc[3];
-                myrank |= ((((mine >> (8u * (key[j] & 3u))) & 0xffu) - 1u) & 0xffu) << (8u * j);      // (meaningless for key 0: never used)
+                rank = ((mine >> (8u * (key & 3u))) & 0xffu) - 1u;            // (meaningless for key 0: never used)
                 const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)inc[0], 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)inc[1], 63);
                 const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)inc[2], 63), t3 = (uint32_t)__builtin_amdgcn_readlane((int)inc[3], 63);
                 const uint32_t lw = (lane >> 2) & 3u;
                 const uint32_t tw = lw == 0 ? t0 : lw == 1 ? t1 : lw == 2 ? t2 : t3;
-                if (lane < 16u) s_cnt[(lane * kPer + j) * 16u + wave] = (uint16_t)((tw >> (8u * (lane & 3u))) & 0xffu);   // the wave's count of key `lane`
+                count_for_lane = (tw >> (8u * (lane & 3u))) & 0xffu;         // lanes 0..15: the wave's count of key `lane`
+            };
+            // counts[key][trip][wave] -> exclusive scan -> destination of every listed position
+            // (rolled loops and packed state on purpose: unrolled, this phase's registers pushed the walk's into scratch and
+            // cost config 2 -- which never runs this code -- 3 ms)
+#pragma unroll 1
+            for (uint32_t kk0 = 0; kk0 < 16u; kk0 += 4u) {
+                uint32_t key[4];
+                keys_of4(tid + kk0 * kMatchThreads, key);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t kk = kk0 + j;
+                    uint32_t rank, cnt_lane;
+                    wave_key_rank(key[j], rank, cnt_lane);
+                    mykeys |= (uint64_t)key[j] << (4u * kk);
+                    const uint64_t r8 = (uint64_t)(rank & 0xffu) << (8u * (kk & 7u));
+                    if (kk0 < 8u) myrank_lo |= r8; else myrank_hi |= r8;
+                    if (lane < 16u) s_cnt[(lane * 16u + kk) * 16u + wave] = (uint16_t)cnt_lane;
+                }
             }
             __syncthreads();
-            {   // exclusive scan of the 16 x 4 x 16 = 1024 counts, one a thread (key 0's are zero)
-                const uint32_t own = s_cnt[tid];
+            {   // exclusive scan of the 4096 counts, four per thread (key 0's are zero)
+                const uint2 c4 = *reinterpret_cast<const uint2*>(s_cnt + 4 * tid);
+                const uint32_t a = c4.x & 0xffffu, b = c4.x >> 16, c = c4.y & 0xffffu, d = c4.y >> 16;
+                const uint32_t own = a + b + c + d;
                 const uint32_t incl = wave_scan_incl(own);
                 if (lane == 63) s_wtot[wave] = incl;
                 __syncthreads();
                 uint32_t wbase = 0, total = 0;
                 for (uint32_t i = 0; i < kMatchThreads / 64; i++) { const uint32_t w = s_wtot[i]; wbase += i < wave ? w : 0u; total += w; }
                 nlist = __builtin_amdgcn_readfirstlane(total);
-                s_cnt[tid] = (uint16_t)(wbase + incl - own);
+                const uint32_t ex = wbase + incl - own;
+                *reinterpret_cast<uint2*>(s_cnt + 4 * tid) = make_uint2(ex | (ex + a) << 16, (ex + a + b) | (ex + a + b + c) << 16);
             }
             __syncthreads();
-#pragma unroll
-            for (uint32_t j = 0; j < kPer; j++)
-                if (key[j]) perm[((uint32_t)s_cnt[(key[j] * kPer + j) * 16u + wave] + ((myrank >> (8u * j)) & 0xffu)) & (kTile - 1u)] = (uint16_t)(tid + j * kMatchThreads);   // (< nlist by construction; masked all the same)
+#pragma unroll 1
+            for (uint32_t kk = 0; kk < 16u; kk++) {
+                const uint32_t key = (uint32_t)(mykeys >> (4u * kk)) & 15u, rank = (uint32_t)((kk < 8u ? myrank_lo : myrank_hi) >> (8u * (kk & 7u))) & 0xffu;
+                if (key) perm[((uint32_t)s_cnt[(key * 16u + kk) * 16u + wave] + rank) & (kTile - 1u)] = (uint16_t)(tid + kk * kMatchThreads);   // (< nlist by construction; masked all the same)
+            }
             __syncthreads();
         }
         auto search_and_store = [&](uint32_t p, bool active) {
             uint32_t e128 = 0, e32 = 0;
-            lz_search_wave(sd8, slink, org, p, L, active, e128, e32);
+            lz_search_wave(sdata, slink, org, p, L, active, e128, e32);
             if (e128) {
                 ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
             }
         };
         if (sorted_order) {
-            for (uint32_t kk = 0; kk < kPer; kk++) {
+            for (uint32_t kk = 0; kk < 16u; kk++) {
                 const uint32_t idx = tid + kk * kMatchThreads;
                 if (__ballot(idx < nlist) == 0) break;
                 search_and_store(idx < nlist ? ts + (uint32_t)perm[idx] : ts, idx < nlist);
@@ -766,32 +749,33 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             // Sparse tile (incompressible data: a position has one predecessor in range on average, most
             // have none or one, a few have five).  In natural order a wave's trip lasts as long as its
             // longest chain and most lanes idle (12% VALU lane utilisation on random bytes).  So a wave
-            // first screens its 256 positions, four a lane with every read in flight together:
+            // first screens its 1024 positions, four trips' reads in flight at a time:
             //   no candidate in range              -> no record, done;
             //   one candidate, trigram differs     -> no record, done (the walk would end on it);
             //   anything else                      -> onto the wave's work list in LDS,
-            // and then runs the full search over the list, 64 entries a trip.
-            constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 448 >= a wave's 256 positions
-            static_assert(kListCap >= kTile / (kMatchThreads / 64u), "a wave's whole share of a tile fits its list");
+            // and then runs the full search over the list, 64 entries a trip.  The list is bounded
+            // (kListCap entries): it is drained early whenever the next four trips might not fit.
+            constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 448
             uint16_t* wl = s_cnt + wave * kListCap;
             uint32_t nl = 0;                                                               // wave-uniform
-            auto drain = [&]() {
+            auto drain = [&](bool all) {                                 // all: the tile is over; else whole trips only, the rest waits
                 // The list is refined in place before it is searched, 64 entries a trip with every lane busy: an entry whose
                 // first two candidates both differ from it in the trigram's middle byte and have no third behind them cannot match (the
                 // walk would end on them with nothing found) -- on random bytes that is three entries in four, at a sixth
                 // of the cost of a search trip.  Survivors are packed to the front (a trip reads its entries before it writes).
+                const uint32_t n_proc = all ? nl : nl & ~63u;               // (a ragged last trip ran a quarter of its lanes)
                 uint32_t ns = 0;
-                for (uint32_t i = lane; i - lane < nl; i += 64u) {
-                    const bool valid = i < nl;
+                for (uint32_t i = lane; i - lane < n_proc; i += 64u) {
+                    const bool valid = i < n_proc;
                     const uint32_t q = valid ? (uint32_t)wl[i] : 0u, p = ts + q, pi = p - org;
                     const uint32_t floor1 = max(p + 1u, kMaxDist + 1u) - kMaxDist;               // a link >= this is a candidate in range
-                    const uint32_t scan = d8_byte(sd8, pi + 1u);                                   // (one byte again: see the screening pass)
+                    const uint32_t scan = sdata[pi + 1u];                                         // (one byte again: see the screening pass)
                     const uint32_t l1 = slink[pi];
                     const uint32_t li1 = valid ? l1 - org : pi;                                   // listed: its first candidate is in range
-                    const uint32_t l2 = slink[li1], cw1 = d8_byte(sd8, li1 + 1u);
+                    const uint32_t l2 = slink[li1], cw1 = sdata[li1 + 1u];
                     const bool in2 = l2 >= floor1;
                     const uint32_t li2 = in2 ? l2 - org : pi;
-                    const uint32_t l3 = slink[li2], cw2 = d8_byte(sd8, li2 + 1u);
+                    const uint32_t l3 = slink[li2], cw2 = sdata[li2 + 1u];
                     uint32_t v = l3 >= floor1 ? scan : cw2;
                     v = in2 ? v : cw1;
                     v = cw1 == scan ? scan : v;
@@ -801,22 +785,25 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     ns += (uint32_t)__popcll(m);
                 }
                 for (uint32_t i = lane; i - lane < ns; i += 64u) search_and_store(i < ns ? ts + (uint32_t)wl[i] : ts, i < ns);
-                nl = 0;
+                const uint32_t rem = nl - n_proc;                            // < 64 entries go to the front and wait for company
+                const uint32_t keepq = lane < rem ? (uint32_t)wl[n_proc + lane] : 0u;
+                if (lane < rem) wl[lane] = (uint16_t)keepq;
+                nl = rem;
             };
-            // A lane screens four consecutive positions: their links are one 8-byte read, their trigrams come out of
-            // one 8-byte word of the D8 window.  Tests are selects on compare masks -- no flag words, no short-circuit logic
-            // (as bool tests and guarded reads this pass was mostly exec-mask bookkeeping on the CU's one scalar unit) -- and
-            // "no candidate" in all its forms (NIL, too far, no trigram, behind zlib's slid window) is one comparison:
-            // link >= floor, with floor(p) = max(1, p - MAX_DIST); a second candidate is in range iff link2 > limit(p),
-            // i.e. link2 >= floor(p + 1).
+            // A lane screens four consecutive positions a trip: their links are one 8-byte read, their trigrams come out of
+            // two words.  Tests are selects on compare masks -- no flag words, no short-circuit logic (as bool tests and
+            // guarded reads this pass was mostly exec-mask bookkeeping on the CU's one scalar unit) -- and "no candidate"
+            // in all its forms (NIL, too far, no trigram, behind zlib's slid window) is one comparison: link >= floor, with
+            // floor(p) = max(1, p - MAX_DIST); a second candidate is in range iff link2 > limit(p), i.e. link2 >= floor(p + 1).
             const uint32_t last_ok = L >= kMinMatch ? min(te, L - (kMinMatch - 1u)) : 0u;
             const uint32_t n_ok = __builtin_amdgcn_readfirstlane(last_ok > ts ? last_ok - ts : 0u);   // the tile's positions with a trigram
-            const uint32_t qb = wave * (kTile / (kMatchThreads / 64u));                       // this wave's 256 positions (wave-uniform)
-            if (qb < n_ok) {
+            for (uint32_t t4 = 0; t4 < 4u; t4++) {
+                const uint32_t qb = wave * 1024u + t4 * 256u;                              // wave-uniform
+                if (qb >= n_ok) break;
+                if (nl + 256u > kListCap) drain(false);
                 const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = p0 - org;            // wi: window index, a multiple of 4
                 const uint2 lk2 = *reinterpret_cast<const uint2*>(slink + wi);
-                const uint2 ww = d8_pair(sd8, wi);
-                const uint32_t w0 = ww.x, w1 = ww.y;
+                const uint32_t w0 = reinterpret_cast<const uint32_t*>(sdata + wi)[0], w1 = reinterpret_cast<const uint32_t*>(sdata + wi)[1];
                 uint32_t l1[4] = {lk2.x & 0xffffu, lk2.x >> 16, lk2.y & 0xffffu, lk2.y >> 16};
                 if (qb + 256u > n_ok) {                                                   // the chunk's last positions
 #pragma unroll
@@ -838,7 +825,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     okm[j] = l1[j] >= floor_[j] ? 0xffffffffu : 0u;
                     const uint32_t li = okm[j] ? l1[j] - org : wi + j;                    // a readable stand-in for positions out of play
                     l2[j] = slink[li];
-                    cb[j] = d8_byte(sd8, li + 1u);
+                    cb[j] = sdata[li + 1u];
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
@@ -850,7 +837,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     nl += (uint32_t)__popcll(m);
                 }
             }
-            drain();
+            drain(true);
         }
         __syncthreads();
         for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads) {
@@ -866,20 +853,18 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         if (delta) {
             ZWZ_TILE_RANGE(t)
             (void)dlo; (void)llo;
-            const uint32_t dn = 2u * (dhi - (new_org >> 4)), ln = lhi - (new_org >> 3);   // 16-byte LDS vectors that stay (a data vector is two)
-            const uint32_t dsh = 2u * (delta >> 4), lsh = delta >> 3;
-            constexpr uint32_t kMove = 5;                                                 // <= 4612 / 4578 vectors over 1024 threads
-            static_assert(kMove * kMatchThreads * 16u >= 2u * kMatchWinData && kMove * kMatchThreads * 16u >= kMatchLinkBytes, "the slide moves the whole window");
-            uint4 rd[kMove] = {z4, z4, z4, z4, z4}, rl[kMove] = {z4, z4, z4, z4, z4};
+            const uint32_t dn = dhi - (new_org >> 4), ln = lhi - (new_org >> 3);   // vectors that stay
+            const uint32_t dsh = delta >> 4, lsh = delta >> 3;
+            uint4 rd[4] = {z4, z4, z4, z4}, rl[6] = {z4, z4, z4, z4, z4, z4};
 #pragma unroll
-            for (uint32_t u = 0; u < kMove; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) rd[u] = sd4[i + dsh]; }
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) rd[u] = sd4[i + dsh]; }
 #pragma unroll
-            for (uint32_t u = 0; u < kMove; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) rl[u] = sl4[i + lsh]; }
+            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) rl[u] = sl4[i + lsh]; }
             __syncthreads();
 #pragma unroll
-            for (uint32_t u = 0; u < kMove; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) sd4[i] = rd[u]; }
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) sd4[i] = rd[u]; }
 #pragma unroll
-            for (uint32_t u = 0; u < kMove; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) sl4[i] = rl[u]; }
+            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) sl4[i] = rl[u]; }
             org = new_org;
         }
     }
