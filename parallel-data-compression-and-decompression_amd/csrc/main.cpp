@@ -26,6 +26,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
 #include "../../include/zwz.h"
 
 namespace {
@@ -198,8 +201,69 @@ struct Rendezvous {
     }
 };
 
+// RCCL over xGMI for the ranks' few collectives (north star): the list CONTENTS broadcast from rank 0
+// (the reference broadcasts the path and reads a shared file system, main.cpp:24-39), the completion status all-reduced
+// (MPI_Barrier, main.cpp:144), and zwz_decompress_dir_ranked's all-gather.  The communicator's 128-byte id is the one
+// thing that still travels through the marker-file handshake above (an MPI launcher would carry it out of band).
+// Used when every rank has a GPU of its own; ranks that share a device (RCCL refuses those) keep to the files.
+struct Rccl {
+    ncclComm_t comm = nullptr; hipStream_t stream = nullptr; int rank = 0, world = 1; bool on = false;
+    static std::string hex(const void* p, size_t n) {
+        static const char* d = "0123456789abcdef"; std::string s; const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; i++) { s += d[b[i] >> 4]; s += d[b[i] & 15]; }
+        return s;
+    }
+    static bool unhex(const std::string& s, void* p, size_t n) {
+        if (s.size() != 2 * n) return false;
+        auto v = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
+        for (size_t i = 0; i < n; i++) static_cast<unsigned char*>(p)[i] = (unsigned char)(v(s[2 * i]) << 4 | v(s[2 * i + 1]));
+        return true;
+    }
+    bool init(const ncclUniqueId& id, int r, int w) {
+        rank = r; world = w;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        on = ncclCommInitRank(&comm, w, id, r) == ncclSuccess;
+        return on;
+    }
+    template <class F> bool with_dev(size_t bytes, F&& f) {          // a device scratch buffer for one collective
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) return false;
+        const bool ok = f(d) && hipStreamSynchronize(stream) == hipSuccess;
+        (void)hipFree(d);
+        return ok;
+    }
+    bool broadcast(std::string& bytes) {                            // rank 0's bytes on every rank
+        uint64_t n = rank == 0 ? bytes.size() : 0;
+        if (!with_dev(8, [&](void* d) {
+                return hipMemcpy(d, &n, 8, hipMemcpyHostToDevice) == hipSuccess && ncclBroadcast(d, d, 8, ncclChar, 0, comm, stream) == ncclSuccess &&
+                       hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(&n, d, 8, hipMemcpyDeviceToHost) == hipSuccess; })) return false;
+        bytes.resize((size_t)n);
+        return with_dev((size_t)n, [&](void* d) {
+            if (rank == 0 && n && hipMemcpy(d, bytes.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return false;
+            if (n && ncclBroadcast(d, d, (size_t)n, ncclChar, 0, comm, stream) != ncclSuccess) return false;
+            return hipStreamSynchronize(stream) == hipSuccess && (!n || hipMemcpy(&bytes[0], d, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess); });
+    }
+    int allgather(const uint64_t* mine, uint64_t* all, uint32_t count) {
+        const size_t one = (size_t)count * 8;
+        return with_dev(one * (size_t)(world + 1), [&](void* d) {
+            char* send = static_cast<char*>(d) + one * (size_t)world;
+            return hipMemcpy(send, mine, one, hipMemcpyHostToDevice) == hipSuccess && ncclAllGather(send, d, count, ncclUint64, comm, stream) == ncclSuccess &&
+                   hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(all, d, one * (size_t)world, hipMemcpyDeviceToHost) == hipSuccess; }) ? 0 : -1;
+    }
+    int worst_status(int rc) {                                      // barrier + every rank learns whether any rank failed
+        int64_t v = rc != 0;
+        const bool ok = with_dev(8, [&](void* d) {
+            return hipMemcpy(d, &v, 8, hipMemcpyHostToDevice) == hipSuccess && ncclAllReduce(d, d, 1, ncclInt64, ncclSum, comm, stream) == ncclSuccess &&
+                   hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost) == hipSuccess; });
+        return !ok ? 3 : (rc ? rc : (v ? 2 : 0));
+    }
+    void done() { if (comm) ncclCommDestroy(comm); if (stream) (void)hipStreamDestroy(stream); comm = nullptr; stream = nullptr; on = false; }
+};
+
+struct Exchange { Rendezvous* rv; Rccl* nc; };
 int exchange_cb(void* user, const uint64_t* mine, uint64_t* all, uint32_t count) {
-    return static_cast<Rendezvous*>(user)->allgather(mine, all, count);
+    Exchange* x = static_cast<Exchange*>(user);
+    return x->nc->on ? x->nc->allgather(mine, all, count) : x->rv->allgather(mine, all, count);
 }
 
 }  // namespace
@@ -260,6 +324,17 @@ int main(int argc, char* argv[]) {
     if (trace) fprintf(stderr, "zwz: context ready at %.3f s\n", since());
     if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
+    // ---- RCCL communicator (see struct Rccl): its id rides on the handshake's publication
+    Rccl nc;
+    const char* comm_env = getenv("ZWZ_COMM");
+    const bool want_rccl = rc == ZWZ_OK && (world_size > 1 ? device_count >= world_size : false) && !(comm_env && !strcmp(comm_env, "files"));
+    const bool force_rccl = rc == ZWZ_OK && comm_env && !strcmp(comm_env, "rccl");          // (also with one rank: exercises the path on a 1-GPU box)
+    std::string nccl_hex;
+    if (world_rank == 0 && (want_rccl || force_rccl)) {
+        ncclUniqueId id;
+        if (ncclGetUniqueId(&id) == ncclSuccess) nccl_hex = Rccl::hex(&id, sizeof id);
+    }
+
     if (operation == "compress") {
         char record[4096] = "";
         if (const char* fr = getenv("ZWZ_FILE_RECORD")) snprintf(record, sizeof record, "%s", fr);
@@ -268,32 +343,63 @@ int main(int argc, char* argv[]) {
             if (rc == ZWZ_OK && !record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
             printf("File record saved location: %s\n", record);
             if (trace) fprintf(stderr, "zwz: file list ready at %.3f s\n", since());
-            if (world_size > 1) { rv.payload = record; if (!rv.publish_to_all()) fprintf(stderr, "rank 0: not every rank announced itself; going on\n"); }
+            if (world_size > 1) { rv.payload = std::string(record) + "\t" + nccl_hex; if (!rv.publish_to_all()) fprintf(stderr, "rank 0: not every rank announced itself; going on\n"); }
         } else if (world_size > 1) {   // the reference broadcasts the record path (main.cpp:24-39)
             if (!rv.accept()) { fprintf(stderr, "rank %d: no file list from rank 0\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
-            else snprintf(record, sizeof record, "%s", rv.payload.c_str());
+            else {
+                const size_t tab = rv.payload.find('\t');
+                snprintf(record, sizeof record, "%s", rv.payload.substr(0, tab).c_str());
+                if (tab != std::string::npos) nccl_hex = rv.payload.substr(tab + 1);
+            }
+        }
+        if ((world_size > 1 || force_rccl) && !nccl_hex.empty() && rc == ZWZ_OK) {
+            ncclUniqueId id;
+            if (!Rccl::unhex(nccl_hex, &id, sizeof id) || !nc.init(id, world_rank, world_size)) { fprintf(stderr, "rank %d: RCCL communicator not available, using marker files\n", world_rank); nc.done(); }
+        }
+        std::string private_list;
+        if (nc.on && rc == ZWZ_OK) {
+            // the list's CONTENTS over RCCL: every rank works from a private copy, so the list needs no shared file system
+            std::string listing;
+            if (world_rank == 0) { FILE* f = fopen(record, "rb"); if (f) { char buf[65536]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) listing.append(buf, k); fclose(f); } }
+            if (!nc.broadcast(listing)) { fprintf(stderr, "rank %d: RCCL broadcast of the file list failed\n", world_rank); rc = ZWZ_E_IO; }
+            else if (world_rank != 0) {
+                private_list = "/tmp/zwz_list_r" + std::to_string(world_rank) + "_" + rv.nonce + ".txt";
+                if (!write_atomic(private_list, listing)) { fprintf(stderr, "rank %d: cannot write %s\n", world_rank, private_list.c_str()); rc = ZWZ_E_IO; }
+                else snprintf(record, sizeof record, "%s", private_list.c_str());
+            }
+            if (trace) fprintf(stderr, "zwz: rank %d has the list (%zu bytes) over RCCL\n", world_rank, listing.size());
         }
         if (rc == ZWZ_OK) {
             printf("file_record: %s\n", record);
             if (world_rank < zwz_count_non_empty_lines(record)) rc = zwz_compress_dir(ctx, source_path.c_str(), output_path.c_str(), record, world_rank, world_size);
             else printf("Rank: %d - No file to compress\n", world_rank);
         }
+        if (!private_list.empty()) unlink(private_list.c_str());
     } else {
         // The reference decodes on rank 0 only (main.cpp:61-68).  Here every rank takes its share: whole shards round-robin,
         // or record ranges of a shard when there are fewer shards than ranks (zwz_decompress_dir_ranked).
         if (world_size > 1) {
-            if (world_rank == 0) { if (!rv.publish_to_all()) { fprintf(stderr, "rank 0: not every rank announced itself\n"); if (rc == ZWZ_OK) rc = 3; } }
+            if (world_rank == 0) { rv.payload = "\t" + nccl_hex; if (!rv.publish_to_all()) { fprintf(stderr, "rank 0: not every rank announced itself\n"); if (rc == ZWZ_OK) rc = 3; } }
             else if (!rv.accept()) { fprintf(stderr, "rank %d: rank 0 never showed up\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
+            else { const size_t tab = rv.payload.find('\t'); if (tab != std::string::npos) nccl_hex = rv.payload.substr(tab + 1); }
+        }
+        if ((world_size > 1 || force_rccl) && !nccl_hex.empty() && rc == ZWZ_OK) {
+            ncclUniqueId id;
+            if (!Rccl::unhex(nccl_hex, &id, sizeof id) || !nc.init(id, world_rank, world_size)) { fprintf(stderr, "rank %d: RCCL communicator not available, using marker files\n", world_rank); nc.done(); }
         }
         int bad = 0;
-        if (rc == ZWZ_OK) rc = zwz_decompress_dir_ranked(ctx, source_path.c_str(), output_path.c_str(), world_rank, world_size, world_size > 1 ? exchange_cb : nullptr, &rv, &bad);
+        Exchange ex{&rv, &nc};
+        if (rc == ZWZ_OK) rc = zwz_decompress_dir_ranked(ctx, source_path.c_str(), output_path.c_str(), world_rank, world_size, world_size > 1 ? exchange_cb : nullptr, &ex, &bad);
     }
     if (trace) fprintf(stderr, "zwz: %s done at %.3f s\n", operation.c_str(), since());
     if (rc != ZWZ_OK && rc != 3) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
     zwz_ctx_destroy(ctx);
     if (trace) fprintf(stderr, "zwz: context destroyed at %.3f s\n", since());
 
-    const int job_rc = rv.finish(rc == ZWZ_OK ? 0 : 2);   // MPI_Barrier (main.cpp:144)
+    int my_rc = rc == ZWZ_OK ? 0 : 2;
+    if (nc.on) { my_rc = nc.worst_status(my_rc); if (trace) fprintf(stderr, "zwz: rank %d: job status %d over RCCL\n", world_rank, my_rc); }
+    nc.done();
+    const int job_rc = rv.finish(my_rc);   // MPI_Barrier (main.cpp:144); also removes the handshake's files
     if (world_rank == 0) {   // main.cpp:148-155
         const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         printf("========================================\nOperation: %s\nProcessor Count: %d\nTime Taken: %g seconds\n"

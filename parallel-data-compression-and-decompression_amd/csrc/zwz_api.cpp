@@ -4,8 +4,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace zwz {
 
@@ -28,6 +30,64 @@ int hip_fail(hipError_t e, const char* what) {
 using namespace zwz;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+namespace {
+
+// Known-answer test of lz_links, run once per context.  The kernel's feeders keep input loads in flight across several
+// hand-overs in registers the compiler merely promises not to touch, and its inserter is one block of hand-scheduled
+// assembly: a toolchain change could break either without a diagnostic, and wrong links mean shards that are no longer
+// the reference's.  Three chunks -- text-like with long chains, incompressible, a ragged short one -- go through the
+// kernel and every link is compared with zlib's insert restated on the host (prev[p] = head[h]; head[h] = p).
+int links_self_test(zwz_ctx* c) {
+    const uint32_t lens[3] = {65535u, 40000u, 2049u + 37u};
+    std::vector<uint8_t> h_in(3 * ZWZ_DEV_STRIDE, 0);
+    uint32_t rng = 0x2545f491u;
+    for (uint32_t k = 0; k < 3; k++) {
+        uint8_t* d = h_in.data() + (size_t)k * ZWZ_DEV_STRIDE;
+        for (uint32_t i = 0; i < lens[k]; i++) {
+            rng = rng * 1664525u + 1013904223u;
+            if (k == 1) d[i] = (uint8_t)(rng >> 24);                                   // incompressible
+            else d[i] = (rng >> 28) < 3 && i >= 7 ? d[i - 7 + ((rng >> 20) & 3u)] : (uint8_t)(97u + ((rng >> 16) % 6u));   // six letters and short copies: long chains
+        }
+    }
+    const uint64_t offs[3] = {0, ZWZ_DEV_STRIDE, 2ull * ZWZ_DEV_STRIDE};
+    uint8_t* d_in = nullptr; uint64_t* d_off = nullptr; uint32_t* d_len = nullptr; uint16_t* d_links = nullptr; uint32_t* d_stat = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_links); (void)hipFree(d_stat); };
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), h_in.size());
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_off), sizeof offs);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_len), sizeof lens);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_links), 3 * (size_t)kLinkStride * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), 3 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, h_in.data(), h_in.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offs, sizeof offs, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_len, lens, sizeof lens, hipMemcpyHostToDevice, c->stream);
+    DeflateArgs a{};
+    a.in = d_in; a.in_off = d_off; a.in_len = d_len; a.n = 3; a.links = d_links; a.link_stat = d_stat;
+    if (e == hipSuccess) e = launch_links_only(a, c->stream);
+    std::vector<uint16_t> got(3 * (size_t)kLinkStride);
+    if (e == hipSuccess) e = hipMemcpyAsync(got.data(), d_links, got.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "lz_links self-test");
+    std::vector<uint16_t> head(32768);
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint8_t* d = h_in.data() + (size_t)k * ZWZ_DEV_STRIDE;
+        std::fill(head.begin(), head.end(), (uint16_t)0);
+        for (uint32_t p = 0; p + kMinMatch <= lens[k]; p++) {
+            const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]);
+            const uint16_t want = head[h];
+            head[h] = (uint16_t)p;
+            if (got[(size_t)k * kLinkStride + p] != want) {
+                set_error("zwz_ctx_create: lz_links self-test failed (chunk %u, position %u: link %u, expected %u) -- the kernel's hand-scheduled "
+                          "code does not survive this toolchain", k, p, (unsigned)got[(size_t)k * kLinkStride + p], (unsigned)want);
+                return ZWZ_E_NO_DEVICE;
+            }
+        }
+    }
+    return ZWZ_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -79,6 +139,7 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
             return ZWZ_E_NO_DEVICE;
         }
     }
+    if (e == hipSuccess) { const int rc = links_self_test(c); if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; } }
     for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
     if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create"); zwz_ctx_destroy(c); return rc; }

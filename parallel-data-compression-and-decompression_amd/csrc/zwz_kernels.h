@@ -87,6 +87,7 @@ constexpr size_t kWorkspaceBytesPerChunk =
 hipError_t configure_kernels();
 hipError_t probe_exchange_order(hipStream_t s, bool* holds);   // see exchange_order_probe_kernel
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* stage_events);
+hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,
                             uint32_t* digests, hipStream_t s);

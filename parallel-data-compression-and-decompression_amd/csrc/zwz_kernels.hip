@@ -466,7 +466,8 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
 // word matches (worth a full comparison), the counter reaches its bound, or no lane is left.
 // (The filter word is two adjacent aligned dwords -- ONE ds_read2_b32 into a named register pair, which costs the LDS
 // ~13 cycles under random addresses against 2 x 10 for two ds_read_b32 (tools/exp/gather_rate.hip) -- and an alignbyte:
-// one unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.)
+// one unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.
+// v_alignbyte_b32 looks at the low two bits of its shift operand only, so the byte address itself is the shift.)
 static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
                                                       bool active, uint32_t& e128, uint32_t& e32) {
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
@@ -506,7 +507,6 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
                 "ds_read2_b32 v[90:91], %[b] offset1:1\n\t"                                         \
                 "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"                                      \
                 "ds_read_u16 %[next], %[l]\n\t"                                                     \
-                "v_and_b32 %[a], 3, %[a]\n\t"                                                       \
                 "s_waitcnt lgkmcnt(1)\n\t"                                                          \
                 "v_alignbyte_b32 %[w0], v91, v90, %[a]\n\t"                                         \
                 "v_and_b32 %[w0], %[w0], %[fmask]\n\t"                                              \
@@ -2128,6 +2128,13 @@ hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
     (void)hipFree(d);
     *holds = e == hipSuccess && h[0] == 0;
     return e;
+}
+
+// lz_links alone over a batch (zwz_ctx_create's known-answer test of the hand-scheduled kernel)
+hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
+    return hipGetLastError();
 }
 
 hipError_t configure_kernels() {

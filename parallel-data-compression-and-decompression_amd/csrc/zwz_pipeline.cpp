@@ -79,7 +79,7 @@ public:
     void submit(Group& g, std::function<void()> fn, bool background = false) {
         g.pending.fetch_add(1);
         { std::lock_guard<std::mutex> l(m_); (background ? bg_ : q_).push_back({&g, std::move(fn)}); }
-        cv_.notify_all();
+        cv_.notify_one();
     }
     void wait(Group& g) {
         std::unique_lock<std::mutex> l(m_);
@@ -348,22 +348,19 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
         uint32_t g = g0;
         sl.n_md5[b] = 0;
-        while (g < g1) {
-            const uint32_t fi = file_of(g);
-            File& f = files[fi];
-            const uint32_t c0 = g - f.first_chunk, c1 = std::min(f.nchunks, c0 + (g1 - g));
-            const bool whole = c0 == 0 && c1 == f.nchunks;
-            // units of <= 64 chunks so that big files are read by several workers
-            for (uint32_t u0 = c0; u0 < c1; u0 += 64) {
-                const uint32_t u1 = std::min(c1, u0 + 64);
-                const bool one_unit = whole && u0 == 0 && u1 == c1;
-                if (one_unit && gpu_md5) {
-                    f.gpu_md5 = (int32_t)sl.n_md5[b];
-                    sl.h_files[b][2 * sl.n_md5[b]] = f.first_chunk - g0; sl.h_files[b][2 * sl.n_md5[b] + 1] = f.nchunks;
-                    sl.n_md5[b]++;
-                }
-                const bool hash_here = one_unit && !gpu_md5;
-                pool.submit(read_group[b], [&, fi, b, g0, u0, u1, hash_here] {
+        // A unit = up to 64 chunks of one file (big files are read by several workers); a task = a run of units worth about
+        // 64 chunks or 32 files, whichever comes first (370 000 one-chunk files as 370 000 tasks spent more time in the
+        // pool's queue than in pread()).
+        struct Unit { uint32_t fi, u0, u1; bool hash_here; };
+        std::vector<Unit> batch;
+        uint32_t batch_chunks = 0;
+        auto flush = [&] {
+            if (batch.empty()) return;
+            pool.submit(read_group[b], [&, b, g0, units = std::move(batch)] {
+              for (const Unit& un : units) {
+                const uint32_t fi = un.fi, u0 = un.u0, u1 = un.u1;
+                const bool hash_here = un.hash_here;
+                {
                     const File& ff = files[fi];
                     Md5 m;
                     const int fd = open(ff.full.c_str(), O_RDONLY);
@@ -387,10 +384,31 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
                     }
                     if (fd >= 0) close(fd);
                     if (hash_here) { char hex[33]; m.hex(hex); files[fi].md5 = hex; files[fi].md5_ready->store(1); }
-                });
+                }
+              }
+            });
+            batch.clear(); batch_chunks = 0;
+        };
+        while (g < g1) {
+            const uint32_t fi = file_of(g);
+            File& f = files[fi];
+            const uint32_t c0 = g - f.first_chunk, c1 = std::min(f.nchunks, c0 + (g1 - g));
+            const bool whole = c0 == 0 && c1 == f.nchunks;
+            for (uint32_t u0 = c0; u0 < c1; u0 += 64) {
+                const uint32_t u1 = std::min(c1, u0 + 64);
+                const bool one_unit = whole && u0 == 0 && u1 == c1;
+                if (one_unit && gpu_md5) {
+                    f.gpu_md5 = (int32_t)sl.n_md5[b];
+                    sl.h_files[b][2 * sl.n_md5[b]] = f.first_chunk - g0; sl.h_files[b][2 * sl.n_md5[b] + 1] = f.nchunks;
+                    sl.n_md5[b]++;
+                }
+                batch.push_back({fi, u0, u1, one_unit && !gpu_md5});
+                batch_chunks += u1 - u0;
+                if (batch_chunks >= 64 || batch.size() >= 32) flush();
             }
             g += c1 - c0;
         }
+        flush();
     };
     // a whole file read as ONE unit is hashed by its reader (or the GPU); every other file -- cut by a slice boundary, or
     // read in pieces -- by hash_whole_file.  Those tasks only need the source file, and MD5 is one sequential stream per

@@ -322,3 +322,26 @@ def test_lossless_env_switch_through_the_cli(tmp_path):
     r = subprocess.run([_cli(), "decompress", str(dst), str(back)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "MD5 mismatch" not in r.stderr
     assert open(back / "r.bin", "rb").read() == data
+
+
+def test_cli_rccl_collectives_single_rank(golden_dir, tmp_path):
+    """csrc/main.cpp's RCCL path (list contents broadcast, status all-reduce, decompress all-gather) needs a GPU per rank, so a
+    1-GPU box can only run it as a communicator of ONE rank (ZWZ_COMM=rccl forces it on): every RCCL call is made, the
+    shard must still be the reference's.  With N > 1 ranks on N GPUs the same code runs with real peers."""
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["1"]
+    src = tmp_path / "data" / "src"
+    _write_tree(str(src))
+    rec = tmp_path / "list.txt"
+    rec.write_text(run["sorted_list"])
+    dst, back = tmp_path / "zwz", tmp_path / "back"
+    env = dict(os.environ, ZWZ_COMM="rccl", ZWZ_VERBOSE="1", ZWZ_FILE_RECORD=str(rec))
+    r = subprocess.run([_cli(), "compress", str(src), str(dst)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "over RCCL" in r.stderr, r.stderr
+    got = {n: open(dst / n, "rb").read() for n in sorted(os.listdir(dst))}
+    assert {n: {"size": len(b), "sha256": sha(b)} for n, b in got.items()} == run["shards"]
+    r = subprocess.run([_cli(), "decompress", str(dst), str(back)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "job status 0 over RCCL" in r.stderr, r.stderr
+    for rel, want in run["decoded"].items():
+        b = open(back / rel, "rb").read()
+        assert {"size": len(b), "sha256": sha(b)} == want, rel

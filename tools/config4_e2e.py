@@ -46,7 +46,13 @@ try:
         shutil.copy(listing, os.path.join(work, "list_product.txt"))
     res["product_decompress"] = run([MAIN, "decompress", os.path.join(work, "zwz"), os.path.join(work, "back")])
     print("product:", res["product_compress"], res["product_decompress"], flush=True)
-    if os.path.exists(REF):
+    if os.environ.get("ZWZ_E2E_VERBOSE"):      # the pipeline's own timeline (where the host side spends its time)
+        shutil.rmtree(os.path.join(work, "zwz")); shutil.rmtree(os.path.join(work, "back"))
+        r = subprocess.run([MAIN, "compress", src, os.path.join(work, "zwz")], capture_output=True, text=True, env=dict(os.environ, ZWZ_VERBOSE="1"))
+        res["product_compress_timeline"] = [l for l in r.stderr.splitlines() if l.startswith("zwz:")][:40]
+        r = subprocess.run([MAIN, "decompress", os.path.join(work, "zwz"), os.path.join(work, "back")], capture_output=True, text=True, env=dict(os.environ, ZWZ_VERBOSE="1"))
+        res["product_decompress_timeline"] = [l for l in r.stderr.splitlines() if l.startswith("zwz:")][:40]
+    if os.path.exists(REF) and not os.environ.get("ZWZ_E2E_SKIP_REF"):
         res["reference_compress_1rank"] = run([REF, "compress", src, os.path.join(work, "rzwz")])
         res["lists_identical"] = os.path.exists(os.path.join(work, "list_product.txt")) and open(listing, "rb").read() == open(os.path.join(work, "list_product.txt"), "rb").read()
         res["reference_decompress"] = run([REF, "decompress", os.path.join(work, "rzwz"), os.path.join(work, "rback")])
