@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     uint4* sl4 = reinterpret_cast<uint4*>(slink);
     const uint4* gd4 = reinterpret_cast<const uint4*>(in + in_off[chunk]);                    // 16-byte aligned (API contract)
     const uint4* gl4 = reinterpret_cast<const uint4*>(links + (size_t)chunk * kLinkStride);
-    uint2* ent = entries + (size_t)chunk * kEntryStride;
+    uint32_t* ent4 = reinterpret_cast<uint32_t*>(entries + (size_t)chunk * kEntryStride);   // plane 0: e128 | flag, plane 1 (kEntryStride words on): e32 where it differs
     uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     const uint32_t ntiles = (L + kTile - 1) / kTile;
     const uint32_t dvec_total = (L + 15u) >> 4;     // the slot is readable to L rounded up to 16; bytes past L
@@ -735,7 +735,13 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             uint32_t e128 = 0, e32 = 0;
             lz_search_wave(sdata, slink, org, p, L, active, e128, e32);
             if (e128) {
-                ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
+                // Records go out in work order, one here, one there: what the scatter costs in HBM is the footprint it dirties.
+                // So a position's record is 4 bytes -- e128, with a flag when the short chain's record differs (it rarely
+                // does) -- and e32 lives in a second plane that is touched only then: half the footprint for lz_match to
+                // dirty and for lz_parse to read (round 1: 8-byte pairs, 42 GB written and 21 GB read per text pass).
+                const bool differs = e32 != e128;          // (e128 == 0 implies e32 == 0; readers gate on has128)
+                ent4[p] = e128 | (differs ? kE32Differs : 0u);
+                if (differs) ent4[kEntryStride + p] = e32;
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
             }
         };
@@ -897,7 +903,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     if (chunk >= n) return;
     ParseWaveMem& m = s_mem[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
-    const uint2* ent = entries + (size_t)chunk * kEntryStride;
+    const uint32_t* ent4 = reinterpret_cast<const uint32_t*>(entries + (size_t)chunk * kEntryStride);   // two planes: see lz_match's search_and_store
     const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
@@ -920,16 +926,27 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hm_l >> 32), (int)i);
         return (uint64_t)lo | ((uint64_t)hi << 32);
     };
-    auto fetch = [&](uint32_t w) -> uint2 {          // window w (64 records), zeros past the chunk
-        uint2 e = make_uint2(0u, 0u);
-        hw_pre = 0;
-        if (w < nwords) { hw_pre = hm_word(w); if ((hw_pre >> lane) & 1ull) e = ent[(w << 6) + lane]; }
-        return e;
+    // A window of 64 records arrives in two steps, a block apart: plane 0 (e128 + flag) for every lane with a record, then
+    // plane 1 (e32) for the few lanes whose flag says it differs -- so the second, dependent read has a block's work to hide behind.
+    uint32_t px = 0; uint64_t hw_px = 0;             // plane 0 of the window in flight, and its has128 word
+    auto fetch_x = [&](uint32_t w) {                 // window w, zeros past the chunk
+        px = 0; hw_px = 0;
+        if (w < nwords) { hw_px = hm_word(w); if ((hw_px >> lane) & 1ull) px = ent4[(w << 6) + lane]; }
     };
-    uint2 pre = fetch(0);
+    auto complete = [&](uint32_t w) -> uint2 {       // w = the window px holds
+        const uint32_t x = px & ~kE32Differs;
+        uint32_t y = x;
+        if (px & kE32Differs) y = ent4[kEntryStride + (w << 6) + lane];
+        hw_pre = hw_px;
+        return make_uint2(x, y);
+    };
+    fetch_x(0);
+    uint2 pre = complete(0);
     m.win[lane] = pre;
     uint64_t hw_cur = hw_pre;                        // has128 word of the block being processed
-    pre = fetch(1);
+    fetch_x(1);
+    pre = complete(1);
+    fetch_x(2);
     uint32_t carry_open = 0, n_sym = 0, last_is_match = 0;
     uint32_t* chosen = chosen_of(links, chunk);      // the chosen record of every match, compact, in stream order
     uint32_t n_match = 0;                            // wave-uniform
@@ -952,20 +969,24 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
                     n_sym += 64u * run;
                     const uint32_t nb = blk + run;
                     if (lane == 0) { m.ring_r[slot] = 0; if ((nb << 6) < L) m.ring_r[2 * (nb & 7u)] |= 1u; }
-                    pre = fetch(nb);                 // re-prime the window pipeline at block nb
+                    fetch_x(nb);                     // re-prime the window pipeline at block nb
+                    pre = complete(nb);
                     m.win[((nb << 6) + lane) & 127u] = pre;
                     hw_cur = hw_pre;
-                    pre = fetch(nb + 1u);
+                    fetch_x(nb + 1u);
+                    pre = complete(nb + 1u);
+                    fetch_x(nb + 2u);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     blk = nb - 1u;
                     continue;
                 }
             }
         }
-        m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2 in flight
+        m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2's second plane and blk + 3's first in flight
         const uint64_t hw_blk = hw_cur;
         hw_cur = hw_pre;
-        pre = fetch(blk + 2);
+        pre = complete(blk + 2);
+        fetch_x(blk + 3);
         const bool valid = q < L;
         {   // literal-only block entered at its first position with nothing pending: no walk to do
             const uint32_t slot = 2 * (blk & 7u);
