@@ -10,8 +10,7 @@ namespace zwz {
 
 // Per-chunk strides of the intermediates (elements).  Everything is indexed [chunk][position].
 constexpr uint32_t kLinkStride = 65536;    // uint16 chain links
-constexpr uint32_t kEntryStride = 65536;   // match records per chunk: two planes of kEntryStride 32-bit words (e128 | kE32Differs; e32 where it differs)
-constexpr uint32_t kE32Differs = 0x8000u;  // a free bit of an entry (len uses bits 0-8, dist bits 16-30)
+constexpr uint32_t kEntryStride = 65536;   // uint2 (e128, e32) match records
 constexpr uint32_t kLinksThreads = 576;                            // one inserter wave + eight feeder waves per chunk
 constexpr uint32_t kLinksLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // 32-bit head table + spare slot + two bucket-address/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;

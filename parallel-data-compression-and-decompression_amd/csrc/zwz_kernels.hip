@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     uint4* sl4 = reinterpret_cast<uint4*>(slink);
     const uint4* gd4 = reinterpret_cast<const uint4*>(in + in_off[chunk]);                    // 16-byte aligned (API contract)
     const uint4* gl4 = reinterpret_cast<const uint4*>(links + (size_t)chunk * kLinkStride);
-    uint32_t* ent4 = reinterpret_cast<uint32_t*>(entries + (size_t)chunk * kEntryStride);   // plane 0: e128 | flag, plane 1 (kEntryStride words on): e32 where it differs
+    uint2* ent = entries + (size_t)chunk * kEntryStride;
     uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     const uint32_t ntiles = (L + kTile - 1) / kTile;
     const uint32_t dvec_total = (L + 15u) >> 4;     // the slot is readable to L rounded up to 16; bytes past L
@@ -735,13 +735,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             uint32_t e128 = 0, e32 = 0;
             lz_search_wave(sdata, slink, org, p, L, active, e128, e32);
             if (e128) {
-                // Records go out in work order, one here, one there: what the scatter costs in HBM is the footprint it dirties.
-                // So a position's record is 4 bytes -- e128, with a flag when the short chain's record differs (it rarely
-                // does) -- and e32 lives in a second plane that is touched only then: half the footprint for lz_match to
-                // dirty and for lz_parse to read (round 1: 8-byte pairs, 42 GB written and 21 GB read per text pass).
-                const bool differs = e32 != e128;          // (e128 == 0 implies e32 == 0; readers gate on has128)
-                ent4[p] = e128 | (differs ? kE32Differs : 0u);
-                if (differs) ent4[kEntryStride + p] = e32;
+                ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
             }
         };
@@ -903,7 +897,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     if (chunk >= n) return;
     ParseWaveMem& m = s_mem[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
-    const uint32_t* ent4 = reinterpret_cast<const uint32_t*>(entries + (size_t)chunk * kEntryStride);   // two planes: see lz_match's search_and_store
+    const uint2* ent = entries + (size_t)chunk * kEntryStride;
     const uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
     uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
@@ -926,27 +920,16 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hm_l >> 32), (int)i);
         return (uint64_t)lo | ((uint64_t)hi << 32);
     };
-    // A window of 64 records arrives in two steps, a block apart: plane 0 (e128 + flag) for every lane with a record, then
-    // plane 1 (e32) for the few lanes whose flag says it differs -- so the second, dependent read has a block's work to hide behind.
-    uint32_t px = 0; uint64_t hw_px = 0;             // plane 0 of the window in flight, and its has128 word
-    auto fetch_x = [&](uint32_t w) {                 // window w, zeros past the chunk
-        px = 0; hw_px = 0;
-        if (w < nwords) { hw_px = hm_word(w); if ((hw_px >> lane) & 1ull) px = ent4[(w << 6) + lane]; }
+    auto fetch = [&](uint32_t w) -> uint2 {          // window w (64 records), zeros past the chunk
+        uint2 e = make_uint2(0u, 0u);
+        hw_pre = 0;
+        if (w < nwords) { hw_pre = hm_word(w); if ((hw_pre >> lane) & 1ull) e = ent[(w << 6) + lane]; }
+        return e;
     };
-    auto complete = [&](uint32_t w) -> uint2 {       // w = the window px holds
-        const uint32_t x = px & ~kE32Differs;
-        uint32_t y = x;
-        if (px & kE32Differs) y = ent4[kEntryStride + (w << 6) + lane];
-        hw_pre = hw_px;
-        return make_uint2(x, y);
-    };
-    fetch_x(0);
-    uint2 pre = complete(0);
+    uint2 pre = fetch(0);
     m.win[lane] = pre;
     uint64_t hw_cur = hw_pre;                        // has128 word of the block being processed
-    fetch_x(1);
-    pre = complete(1);
-    fetch_x(2);
+    pre = fetch(1);
     uint32_t carry_open = 0, n_sym = 0, last_is_match = 0;
     uint32_t* chosen = chosen_of(links, chunk);      // the chosen record of every match, compact, in stream order
     uint32_t n_match = 0;                            // wave-uniform
@@ -969,24 +952,20 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
                     n_sym += 64u * run;
                     const uint32_t nb = blk + run;
                     if (lane == 0) { m.ring_r[slot] = 0; if ((nb << 6) < L) m.ring_r[2 * (nb & 7u)] |= 1u; }
-                    fetch_x(nb);                     // re-prime the window pipeline at block nb
-                    pre = complete(nb);
+                    pre = fetch(nb);                 // re-prime the window pipeline at block nb
                     m.win[((nb << 6) + lane) & 127u] = pre;
                     hw_cur = hw_pre;
-                    fetch_x(nb + 1u);
-                    pre = complete(nb + 1u);
-                    fetch_x(nb + 2u);
+                    pre = fetch(nb + 1u);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     blk = nb - 1u;
                     continue;
                 }
             }
         }
-        m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2's second plane and blk + 3's first in flight
+        m.win[(q + 64u) & 127u] = pre;               // window blk + 1 -> LDS, window blk + 2 in flight
         const uint64_t hw_blk = hw_cur;
         hw_cur = hw_pre;
-        pre = complete(blk + 2);
-        fetch_x(blk + 3);
+        pre = fetch(blk + 2);
         const bool valid = q < L;
         {   // literal-only block entered at its first position with nothing pending: no walk to do
             const uint32_t slot = 2 * (blk & 7u);
@@ -1761,10 +1740,23 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
 
+constexpr uint32_t kOwnCap = 1024;         // batch bytes the per-byte owner map covers (a batch is <= 64 symbols: ~300 bytes on text)
+
+static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {          // as wave_scan_incl, with max (0 = identity)
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
+    __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
     uint16_t jump[64 * kWinSlots + 8];       // window offset -> offset of the symbol after the one starting there (pointer doubling)
     uint32_t flag[64 * kWinSlots / 4];       // one byte per window offset: reached from offset 0
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
@@ -1994,11 +1986,40 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 const uint32_t bstart = opos_u;
                 const uint32_t bbytes = opos_new - bstart;
                 opos_u = opos_new;
+                // Which symbol writes a byte: for batches of up to kOwnCap bytes (nearly all) a per-byte map -- every symbol
+                // marks its first byte with 1 + its index, a max-scan carries the marks forward -- so a lookup is one LDS byte;
+                // larger batches search the symbols' start offsets (6 dependent LDS reads).  It matters where matches a few
+                // bytes back refer to each other (smooth "image-like" data): every hop of the chase below is such a lookup.
+                const bool mapped = bbytes <= kOwnCap;                             // wave-uniform
+                if (mapped) {
+                    for (uint32_t i = lane; i < (bbytes + 15u) >> 4; i += 64u) reinterpret_cast<uint4*>(m.ownb)[i] = make_uint4(0, 0, 0, 0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (lane < k) m.ownb[m.pos[lane] - bstart] = (uint8_t)(lane + 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    uint32_t carry = 0;
+                    for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
+                        const uint32_t o = max(wave_scan_max_incl((uint32_t)m.ownb[j0 + lane]), carry);
+                        m.ownb[j0 + lane] = (uint8_t)o;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
                 auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
                     uint32_t lo = 0;
+                    if (mapped) lo = (uint32_t)m.ownb[pos - bstart] - 1u;
+                    else {
 #pragma unroll
-                    for (uint32_t stp = 32; stp >= 1; stp >>= 1) { const uint32_t q = m.pos[(lo + stp) & 63u]; if (q <= pos) lo += stp; }
+                        for (uint32_t stp = 32; stp >= 1; stp >>= 1) { const uint32_t q = m.pos[(lo + stp) & 63u]; if (q <= pos) lo += stp; }
+                    }
                     ov = m.batch[lo]; op = m.pos[lo];
+                };
+                // byte `at` of a match that starts at op with distance d comes from here (the modulo only where a match
+                // overlaps itself: a wave-uniform branch, rare on text)
+                auto source_of = [&](uint32_t at, uint32_t op, uint32_t d, bool live) -> uint32_t {
+                    const uint32_t off = at - op;
+                    uint32_t from = at - d;
+                    if (__ballot(live && off >= d)) from = off < d ? from : op - d + off % (d | (uint32_t)!live);
+                    return from;
                 };
                 bool need_fence = false;
                 for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
@@ -2006,16 +2027,17 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     const bool in = j0 + lane < bbytes;
                     uint32_t ov = 0, op = 0;
                     owner(in ? pos : bstart, ov, op);
-                    uint32_t src = 0; bool lit = ov < 256u;
-                    if (!lit) { const uint32_t d = ov & 0xffffu; src = op - d + ((pos - op) % d); }
+                    bool lit = ov < 256u;
+                    uint32_t src = source_of(pos, op, ov & 0xffffu, in && !lit);
                     // chase references into this batch (wave-uniform loop, lanes drop out as they resolve)
                     while (__ballot(in && !lit && src >= bstart)) {
                         const bool go2 = in && !lit && src >= bstart;
                         uint32_t ov2 = 0, op2 = 0;
                         owner(go2 ? src : bstart, ov2, op2);
+                        const uint32_t s2 = source_of(src, op2, ov2 & 0xffffu, go2 && ov2 >= 256u);
                         if (go2) {
                             if (ov2 < 256u) { lit = true; ov = ov2; }
-                            else { const uint32_t d = ov2 & 0xffffu; src = op2 - d + ((src - op2) % d); }
+                            else src = s2;
                         }
                     }
                     const uint64_t far = __ballot(in && !lit && src + 1u > fenced);
