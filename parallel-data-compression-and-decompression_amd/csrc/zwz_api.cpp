@@ -192,7 +192,7 @@ int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
         if (want > c->ws_chunks) {
             HIPCHK(hipStreamSynchronize(c->stream));
             if (c->workspace) { (void)hipFree(c->workspace); c->workspace = nullptr; c->ws_chunks = 0; }
-            HIPCHK(hipMalloc(&c->workspace, (size_t)want * kWorkspaceBytesPerChunk + 4096));
+            HIPCHK(hipMalloc(&c->workspace, (size_t)want * kWorkspaceBytesPerChunk + kTicketBytes + 8192));
             c->ws_chunks = want;
         }
     }
@@ -325,6 +325,8 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.mst = reinterpret_cast<uint64_t*>(take(n * kMaskWords * 8));
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
     a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+    a.tickets = reinterpret_cast<uint32_t*>(take(kTicketBytes));
+    a.cu_count = c->cu_count;
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));
     a.plans = reinterpret_cast<BlockOut*>(take(n * kMaxBlocks * sizeof(BlockOut)));

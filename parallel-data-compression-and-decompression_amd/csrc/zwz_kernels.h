@@ -69,6 +69,8 @@ struct DeflateArgs {
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
+    uint32_t* tickets;         // kTicketBytes of counters (encode's list of Huffman chunks and its hand-out; zeroed by launch_deflate)
+    uint32_t cu_count;         // sizes the persistent grids (0: 256)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
     // The chosen record of every match symbol, compact and in stream order (lz_parse -> blockify, encode): a chunk's
@@ -80,6 +82,7 @@ struct InflateArgs {
     uint8_t* out; uint64_t out_stride; uint32_t* out_len; uint32_t* status;
 };
 
+constexpr size_t kTicketBytes = 256;
 constexpr size_t kWorkspaceBytesPerChunk =
     (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));

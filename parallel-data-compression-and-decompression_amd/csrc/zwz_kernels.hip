@@ -1423,12 +1423,14 @@ static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpo
 // 4-byte read of the input except the handful of dwords that touch a header.
 // (lane b of every wave holds block b's byte range: the caller read it alongside the chunk's other metadata, so that the
 // copy is two HBM round trips -- metadata, data -- and not five dependent ones; one workgroup per CU has nothing to hide them behind)
+template <uint32_t T>                                   // threads of the workgroup; 16 384 / T output vectors a thread
 static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __restrict__ data, uint32_t L, uint32_t n_blocks,
                                                            uint32_t lane_start, uint32_t lane_end, uint32_t* __restrict__ gout,
                                                            uint32_t* __restrict__ out_len_slot) {
     __shared__ uint32_t s_hb[kMaxBlocks + 1], s_st[kMaxBlocks + 1];   // stream offset of each block header; its first input byte
-    __shared__ uint32_t s_a[kEncodeThreads / 64], s_adler_be;
-    __shared__ unsigned long long s_b[kEncodeThreads / 64];
+    __shared__ uint32_t s_a[T / 64], s_adler_be;
+    __shared__ unsigned long long s_b[T / 64];
+    constexpr uint32_t kRounds = 1024u / T;
     const uint32_t tid = threadIdx.x;
     static_assert(kMaxBlocks == 5, "block ranges are passed in lanes 0..4");
     const uint32_t bs[kMaxBlocks] = {(uint32_t)__builtin_amdgcn_readlane((int)lane_start, 0), (uint32_t)__builtin_amdgcn_readlane((int)lane_start, 1),
@@ -1452,28 +1454,30 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
     // Not for a chunk whose stream reaches the 65 535-byte cap before the trailer starts (every full incompressible
     // chunk: 65 535 + 5 headers): the reference cuts the checksum off, so the input is read once, by the copy below.
     if (s_hb[n_blocks] < kChunk) {                            // workgroup-uniform
-        uint32_t w[16];
-#pragma unroll
-        for (uint32_t u = 0; u < 16; u++) {
-            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-            w[u] = i < L ? d32[i >> 2] : 0u;                  // slot readable to L rounded up to 16
-        }
         uint32_t a_sum = 0; unsigned long long b_sum = 0;
+        for (uint32_t r = 0; r < kRounds; r++) {
+            uint32_t w[16];
 #pragma unroll
-        for (uint32_t u = 0; u < 16; u++) {
-            const uint32_t i = (tid + u * kEncodeThreads) * 4u;
-            uint32_t x = w[u];
-            if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
-            const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
-            a_sum += sum;
-            b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
+            for (uint32_t u = 0; u < 16; u++) {
+                const uint32_t i = (tid + (u + 16u * r) * T) * 4u;
+                w[u] = i < L ? d32[i >> 2] : 0u;              // slot readable to L rounded up to 16
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 16; u++) {
+                const uint32_t i = (tid + (u + 16u * r) * T) * 4u;
+                uint32_t x = w[u];
+                if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
+                const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
+                a_sum += sum;
+                b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
+            }
         }
         for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
         if (lane_id() == 0) { s_a[tid >> 6] = a_sum; s_b[tid >> 6] = b_sum; }
         __syncthreads();
         if (tid == 0) {
             unsigned long long a = 1, b = L;
-            for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_a[i]; b += s_b[i]; }
+            for (uint32_t i = 0; i < T / 64; i++) { a += s_a[i]; b += s_b[i]; }
             s_adler_be = __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
         }
         __syncthreads();
@@ -1496,10 +1500,12 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
     // unless it touches a header or the trailer; all reads in flight before the first is used.  (Dword by dword -- two
     // reads and a store per four bytes -- the copy ran at 3.5 TB/s of traffic; the memory pipeline counts instructions.)
     const uint32_t n_v = (n_out + 15u) >> 4;
+  for (uint32_t r = 0; r < kRounds; r++) {
+    if ((4u * r) * T >= n_v) break;
     uint4 qa[4]; uint32_t qb[4], sh[4]; bool fast[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++) {
-        const uint32_t o = (tid + u * kEncodeThreads) * 16u;
+        const uint32_t o = (tid + (u + 4u * r) * T) * 16u;
         uint32_t b = block_at(o);
         if (b >= n_blocks) b = n_blocks - 1u;
         const uint32_t lo = s_hb[b] + 5u, hi = s_hb[b + 1];
@@ -1512,7 +1518,7 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++) {
-        const uint32_t ov = tid + u * kEncodeThreads, o = ov * 16u;
+        const uint32_t ov = tid + (u + 4u * r) * T, o = ov * 16u;
         if (ov >= n_v) continue;
         uint4 v;
         if (fast[u]) {
@@ -1529,15 +1535,46 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
         }
         reinterpret_cast<uint4*>(gout)[ov] = v;
     }
+  }
 }
 
-__global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+// encode, first kernel: chunks whose blocks are all stored (incompressible data) are copied here, by small workgroups without
+// the bit-packer's LDS -- eight to a CU, so that one's two HBM round trips hide behind the others' (inside encode_kernel, two
+// 81 KB workgroups a CU, a stored chunk cost ~12 us whatever its length: 1.7 ms per 50 000).  Every other chunk goes onto the
+// list encode_kernel works through.
+constexpr uint32_t kEncStoredThreads = 256;
+constexpr uint32_t kTicketHuffCount = 0, kTicketHuffNext = 1;      // indices into DeflateArgs::tickets
+
+__global__ __launch_bounds__(kEncStoredThreads) void encode_stored_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                          const uint32_t* __restrict__ in_len, const ChunkInfo* __restrict__ info,
+                                                                          const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
+                                                                          uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
+                                                                          uint32_t* __restrict__ huff_list, uint32_t* __restrict__ tickets) {
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t L = in_len[chunk], n_blocks = info[chunk].n_blocks;
+    const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks;
+    const BlockOut* bo = plans + (size_t)chunk * kMaxBlocks;
+    // lane b looks at block b (every wave: the copy wants the ranges in each wave's lanes); these loads do not wait for n_blocks
+    const uint32_t lb = lane_id() < kMaxBlocks ? lane_id() : 0u;
+    const uint32_t my_type = bo[lb].type, my_start = bi[lb].start, my_end = bi[lb].end;
+    const bool all_stored = n_blocks > 0 && __builtin_amdgcn_ballot_w64(lane_id() < n_blocks && my_type != kStored) == 0;   // workgroup-uniform
+    if (!all_stored) {
+        if (threadIdx.x == 0) huff_list[atomicAdd(&tickets[kTicketHuffCount], 1u)] = chunk;
+        return;
+    }
+    encode_stored_chunk<kEncStoredThreads>(in + in_off[chunk], L, n_blocks, my_start, my_end,
+                                           reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
+}
+
+__global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
                                                                 const ChunkInfo* __restrict__ info,
                                                                 const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
                                                                 uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
-                                                                const uint16_t* __restrict__ links) {
+                                                                const uint16_t* __restrict__ links,
+                                                                const uint32_t* __restrict__ huff_list, uint32_t* __restrict__ tickets) {
+    // Persistent (two workgroups a CU by LDS): the chunks encode_stored_kernel left on the list, handed out by a ticket counter.
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
     uint64_t* s_sym = reinterpret_cast<uint64_t*>(smem + kOutWords * 4);          // kMaskWords
@@ -1551,7 +1588,15 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
     __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
 
-    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t s_item;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_items = tickets[kTicketHuffCount];       // final: encode_stored_kernel has finished
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(&tickets[kTicketHuffNext], 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= n_items) break;
+    const uint32_t chunk = huff_list[item];
     const uint32_t L = in_len[chunk];
     const uint32_t nwords = (L + 63) >> 6;
     const ChunkInfo ci = info[chunk];
@@ -1561,16 +1606,6 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     const uint32_t* chosen = chosen_of(links, chunk);
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
-
-    {   // wave-uniform: are all blocks stored?  Lane b looks at block b; these loads do not wait for ci.
-        const uint32_t lb = lane_id() < kMaxBlocks ? lane_id() : 0u;
-        const uint32_t my_type = bo[lb].type, my_start = bi[lb].start, my_end = bi[lb].end;
-        const bool all_stored = ci.n_blocks > 0 && __builtin_amdgcn_ballot_w64(lane_id() < ci.n_blocks && my_type != kStored) == 0;
-        if (all_stored) {
-            encode_stored_chunk(data, L, ci.n_blocks, my_start, my_end, reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
-            return;
-        }
-    }
     for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
     // symbol ranks again (cheaper to recompute than to round-trip through HBM), and match ranks: thread t holds mask
     // word t, wave w's words are exactly its 4096-position segment below
@@ -1729,6 +1764,8 @@ __global__ __launch_bounds__(kEncodeThreads) void encode_kernel(const uint8_t* _
     const uint32_t n_out = s_total_bytes < kChunk ? s_total_bytes : kChunk;
     uint32_t* gout = reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride);
     for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
+    __syncthreads();                                          // everyone has read s_item, s_total_bytes and s_out
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2190,6 +2227,7 @@ hipError_t configure_kernels() {
 
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
     if (a.n == 0) return hipSuccess;
+    ZWZ_TRY(hipMemsetAsync(a.tickets, 0, kTicketBytes, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
@@ -2205,8 +2243,14 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + 63u) / 64u), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
     hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
-    hipLaunchKernelGGL(encode_kernel, dim3(a.n), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
-                       a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links);
+    {
+        uint32_t* huff_list = reinterpret_cast<uint32_t*>(a.perm);          // lz_match's work-order array is dead by now
+        hipLaunchKernelGGL(encode_stored_kernel, dim3(a.n), dim3(kEncStoredThreads), 0, s, a.in, a.in_off, a.in_len, a.info, a.blocks, a.plans,
+                           a.out, a.out_stride, a.out_len, huff_list, a.tickets);
+        const uint32_t slots = 2u * (a.cu_count ? a.cu_count : 256u);
+        hipLaunchKernelGGL(encode_kernel, dim3(a.n < slots ? a.n : slots), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
+                           a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links, huff_list, a.tickets);
+    }
     if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
     return hipGetLastError();
 }
