@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             const uint32_t last_ok = L >= kMinMatch ? min(te, L - (kMinMatch - 1u)) : 0u;
             const uint32_t n_ok = __builtin_amdgcn_readfirstlane(last_ok > ts ? last_ok - ts : 0u);   // the tile's positions with a trigram
             for (uint32_t t4 = 0; t4 < 4u; t4++) {
-                const uint32_t qb = wave * 1024u + t4 * 256u;                              // wave-uniform
+                const uint32_t qb = t4 * 4096u + wave * 256u;                              // wave-uniform; the waves interleave: later positions have more history
                 if (qb >= n_ok) break;
                 if (nl + 256u > kListCap) drain(false);
                 const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = p0 - org;            // wi: window index, a multiple of 4
