@@ -39,50 +39,62 @@ namespace {
 // the reference's.  Three chunks -- text-like with long chains, incompressible, a ragged short one -- go through the
 // kernel and every link is compared with zlib's insert restated on the host (prev[p] = head[h]; head[h] = p).
 int links_self_test(zwz_ctx* c) {
-    const uint32_t lens[3] = {65535u, 40000u, 2049u + 37u};
-    std::vector<uint8_t> h_in(3 * ZWZ_DEV_STRIDE, 0);
+    // three workgroups for eight chunks: each one runs on from chunk to chunk (full, short, one-block, empty and tiny ones)
+    constexpr uint32_t K = 8;
+    const uint32_t lens[K] = {65535u, 40000u, 0u, 2049u + 37u, 5u, 6144u, 65535u, 2u};
+    std::vector<uint8_t> h_in((size_t)K * ZWZ_DEV_STRIDE, 0);
     uint32_t rng = 0x2545f491u;
-    for (uint32_t k = 0; k < 3; k++) {
+    uint64_t offs[K];
+    for (uint32_t k = 0; k < K; k++) {
         uint8_t* d = h_in.data() + (size_t)k * ZWZ_DEV_STRIDE;
+        offs[k] = (uint64_t)k * ZWZ_DEV_STRIDE;
         for (uint32_t i = 0; i < lens[k]; i++) {
             rng = rng * 1664525u + 1013904223u;
-            if (k == 1) d[i] = (uint8_t)(rng >> 24);                                   // incompressible
+            if (k & 1u) d[i] = (uint8_t)(rng >> 24);                                   // incompressible
             else d[i] = (rng >> 28) < 3 && i >= 7 ? d[i - 7 + ((rng >> 20) & 3u)] : (uint8_t)(97u + ((rng >> 16) % 6u));   // six letters and short copies: long chains
         }
     }
-    const uint64_t offs[3] = {0, ZWZ_DEV_STRIDE, 2ull * ZWZ_DEV_STRIDE};
     uint8_t* d_in = nullptr; uint64_t* d_off = nullptr; uint32_t* d_len = nullptr; uint16_t* d_links = nullptr; uint32_t* d_stat = nullptr;
     auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_links); (void)hipFree(d_stat); };
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), h_in.size());
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_off), sizeof offs);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_len), sizeof lens);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_links), 3 * (size_t)kLinkStride * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), 3 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_links), K * (size_t)kLinkStride * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), K * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, h_in.data(), h_in.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, offs, sizeof offs, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_len, lens, sizeof lens, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_links, 0xa5, K * (size_t)kLinkStride * sizeof(uint16_t), c->stream);
     DeflateArgs a{};
-    a.in = d_in; a.in_off = d_off; a.in_len = d_len; a.n = 3; a.links = d_links; a.link_stat = d_stat;
+    a.in = d_in; a.in_off = d_off; a.in_len = d_len; a.n = K; a.links = d_links; a.link_stat = d_stat; a.cu_count = 3;
     if (e == hipSuccess) e = launch_links_only(a, c->stream);
-    std::vector<uint16_t> got(3 * (size_t)kLinkStride);
+    std::vector<uint16_t> got(K * (size_t)kLinkStride);
+    uint32_t stat[K] = {};
     if (e == hipSuccess) e = hipMemcpyAsync(got.data(), d_links, got.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stat, d_stat, sizeof stat, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return hip_fail(e, "lz_links self-test");
     std::vector<uint16_t> head(32768);
-    for (uint32_t k = 0; k < 3; k++) {
+    for (uint32_t k = 0; k < K; k++) {
         const uint8_t* d = h_in.data() + (size_t)k * ZWZ_DEV_STRIDE;
         std::fill(head.begin(), head.end(), (uint16_t)0);
+        uint32_t linked = 0;
         for (uint32_t p = 0; p + kMinMatch <= lens[k]; p++) {
             const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]);
             const uint16_t want = head[h];
             head[h] = (uint16_t)p;
+            linked += want != 0;
             if (got[(size_t)k * kLinkStride + p] != want) {
                 set_error("zwz_ctx_create: lz_links self-test failed (chunk %u, position %u: link %u, expected %u) -- the kernel's hand-scheduled "
                           "code does not survive this toolchain", k, p, (unsigned)got[(size_t)k * kLinkStride + p], (unsigned)want);
                 return ZWZ_E_NO_DEVICE;
             }
         }
+        for (uint32_t p = lens[k] >= kMinMatch ? lens[k] - (kMinMatch - 1u) : 0u; p < lens[k]; p++) {   // the last positions have no trigram: NIL
+            if (got[(size_t)k * kLinkStride + p] != 0) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: a link behind the last trigram)", k); return ZWZ_E_NO_DEVICE; }
+        }
+        if (stat[k] != linked) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: %u linked positions counted, %u expected)", k, stat[k], linked); return ZWZ_E_NO_DEVICE; }
     }
     return ZWZ_OK;
 }

@@ -77,8 +77,9 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // waves (four positions a lane a block) turn input bytes into the bucket ADDRESSES of the next 2048 positions in an LDS buffer and move the finished links
 // of the previous 2048 positions out of that buffer to HBM, both as 16-byte vectors; the two roles meet at a barrier
 // every 2048 positions (two buffers alternate).  Positions past the last trigram are sent to bucket 0: they are the last
-// positions of the chunk, nothing reads the table after them, and the feeders zero their links on the way out -- so the
-// inserter needs no validity logic.  The 128 KiB table leaves room for one chunk per CU.
+// positions of the chunk, nothing of this chunk reads the table after them (the next chunk's epoch disowns them, below), and
+// the feeders zero their links on the way out -- so the inserter needs no validity logic.  The 128 KiB table leaves room for
+// one workgroup per CU.
 // The compiler's own wait insertion drains to 0 at loop headers and right behind loads it schedules early, which is why the
 // inserter's loop and the feeders' input loads are inline asm with counted waits; what keeps that sound:
 //   * every step / hand-over issues exactly the same operations in the same order, whatever its lanes hold;
@@ -87,23 +88,42 @@ static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 constexpr uint32_t kLinksBlock = 2048;             // positions per hand-over between the inserter and the feeders
 constexpr uint32_t kLinksNoHash = 0;               // bucket of a position without a trigram (any bucket will do, see above)
 
+// Persistent: workgroup w of G (one per CU) links chunks w, w + G, w + 2G, ... as ONE stream of blocks.  The table is cleared
+// once: a bucket holds (epoch << 16) | position with epoch = 1 + the chunk's index in this workgroup's sequence, and a
+// predecessor that carries another epoch is a leftover of an earlier chunk, i.e. NIL -- the feeders check that on the way
+// out, the inserter never knows where a chunk ends.  So the feeders' three cursors (links out: one block behind the
+// inserter; bucket addresses: one ahead; input requests: four ahead) simply run on into the next chunk.  (A workgroup per
+// chunk paid ~3.5 us per chunk -- dispatch, a 128 KiB clear, an HBM round trip nothing covered, a drained pipeline: a sixth
+// of the kernel.)
 __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
-                                                                 uint32_t* __restrict__ link_stat) {
+                                                                 uint32_t* __restrict__ link_stat /* zeroed by the launcher */, uint32_t n) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
     extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 32-bit buckets + 16 spare bytes
     constexpr uint32_t kHeadBytes = 131072u;
     uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock 32-bit entries: bucket addresses in, links out
-    const uint32_t chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const uint32_t L = in_len[chunk];
-    if (L == 0) { if (tid == 0) link_stat[chunk] = 0; return; }
-    const uint8_t* data = in + in_off[chunk];                                // 16-byte aligned (API contract)
-    uint16_t* lk = links + (size_t)chunk * kLinkStride;
-    const uint32_t Lr = (L + 15u) & ~15u;                                    // the slot is readable this far
-    const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
-
-    if (tid == 0) link_stat[chunk] = 0;       // the feeder waves add their counts at the end
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t G = gridDim.x;                                            // <= n: every workgroup has a first chunk
+    // A cursor: block k of the chunk c = blockIdx.x + j G, the g-th block of this workgroup's stream (the input register sets
+    // rotate with g mod 3, the two hand-over buffers alternate with g).  The stream ends on a multiple of three hand-overs;
+    // blocks past its end hash to the no-trigram bucket and are never inserted or written out.
+    // All of it is wave-uniform (scalar loads, scalar registers).
+    struct Cursor { uint32_t c, j, k, g, L, n_blocks; const uint8_t* data; uint16_t* lk; };
+    const uint8_t* const data0 = in + in_off[blockIdx.x];                    // any readable 16 bytes, for requests past the last chunk
+    uint16_t* const lk_spare = links + (size_t)blockIdx.x * kLinkStride + (kLinkStride - 1u);   // position 65 535 does not exist: nobody's link
+    auto enter = [&](Cursor& q) {                                            // settle on chunk q.c or the next one with any bytes
+        for (;;) {
+            if (q.c >= n) { q.L = 0; q.n_blocks = 0xffffffffu; q.data = data0; q.lk = nullptr; return; }   // past the end: stays here
+            q.L = in_len[q.c];
+            q.n_blocks = (q.L + kLinksBlock - 1u) / kLinksBlock;
+            q.data = in + in_off[q.c];                                       // 16-byte aligned (API contract)
+            q.lk = links + (size_t)q.c * kLinkStride;
+            if (q.n_blocks) return;
+            q.c += G; q.j++;
+        }
+    };
+    auto advance = [&](Cursor& q) { q.k++; q.g++; if (q.k >= q.n_blocks) { q.c += G; q.j++; q.k = 0; enter(q); } };
 
     // ---- feeder: input bytes -> registers (asked for hand-overs ahead, see the main loop) -> bucket addresses in LDS;
     // finished links LDS -> HBM
@@ -127,25 +147,26 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     constexpr uint32_t kStoreOps = 1u;                                          // ... and of a flush_block
     constexpr uint32_t kWait = 2u * (kLoadOps + kStoreOps) + kStoreOps;         // operations younger than the awaited set: two whole trips and this trip's store
     const uint32_t fpos = (wave - 1u) * (kLinksBlock / kFeeders) + lane * kPer;   // this lane's share within a block (feeder waves)
-    auto load_block = [&](uint32_t k, auto slot) { // input bytes [2048 k + fpos, + 8) -> register set `slot` (= k mod kAhead)
+    auto load_block = [&](const Cursor& q, auto slot) { // input bytes [2048 k + fpos, + 8) of the cursor's block -> register set `slot` (= g mod kAhead)
         InSet& S = in_ring[decltype(slot)::value];
-        const uint32_t o = k * kLinksBlock + fpos;
-        const uint8_t* pa = data + (o + 4u <= Lr ? o : 0u);
-        const uint8_t* pt = data + (o + 8u <= Lr ? o + 4u : 0u);
+        const uint32_t o = q.k * kLinksBlock + fpos;
+        const uint32_t Lr = (q.L + 15u) & ~15u;                              // the slot is readable this far
+        const uint8_t* pa = q.data + (o + 4u <= Lr ? o : 0u);
+        const uint8_t* pt = q.data + (o + 8u <= Lr ? o + 4u : 0u);
         asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
     };
-    auto pad_stores = [&](uint32_t n) {            // n stores with no effect: zeros over this lane's first link of block 0, before its flush_block writes it
-        for (uint32_t i = 0; i < n; i++) asm volatile("global_store_short %0, %1, off" :: "v"(lk + fpos), "v"(0u) : "memory");
+    auto pad_stores = [&](uint32_t cnt) {          // stores with no effect, where a trip has no links to write out (the counted wait below wants every trip's)
+        for (uint32_t i = 0; i < cnt; i++) asm volatile("global_store_short %0, %1, off" :: "v"(lk_spare), "v"(0u) : "memory");
     };
     typedef __attribute__((address_space(3))) uint8_t* lds_byte_ptr;
     const uint32_t head_base = (uint32_t)(uintptr_t)(lds_byte_ptr) reinterpret_cast<uint8_t*>(head);   // 0: this kernel has no static LDS
     uint32_t* hbuf32 = reinterpret_cast<uint32_t*>(hbuf);                       // 32-bit entries: bucket address in, link out
-    auto hash_block = [&](uint32_t k, auto slot) { // bucket addresses of positions [2048 k + fpos, + 4) from the loaded input
+    auto hash_block = [&](const Cursor& q, auto slot) { // bucket addresses of positions [2048 k + fpos, + 4) from the loaded input
         InSet& S = in_ring[decltype(slot)::value];
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.c), "+v"(S.t) : "n"(kWait) : "memory");
         const uint32_t in_w[2] = {S.c, S.t};
-        const uint32_t o = k * kLinksBlock + fpos;
-        const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram
+        const uint32_t o = q.k * kLinksBlock + fpos, L = q.L;
+        const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram (none past the last chunk)
         uint32_t e[kPer];
 #pragma unroll
         for (uint32_t i = 0; i < kPer; i++) {
@@ -154,19 +175,22 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
             if (i >= n_ok) h = kLinksNoHash;
             e[i] = 4u * h + head_base;                 // the bucket's LDS byte address
         }
-        *reinterpret_cast<uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4*>(hbuf32 + (q.g & 1u) * kLinksBlock + fpos) = make_uint4(e[0], e[1], e[2], e[3]);
     };
     uint32_t linked = 0;                               // feeder: positions of this lane with a chain predecessor
-    auto flush_block = [&](uint32_t k) {           // links of block k: LDS -> HBM, zero where there is no trigram
-        const uint32_t o = k * kLinksBlock + fpos;
+    auto flush_block = [&](const Cursor& q) {      // links of the cursor's block: LDS -> HBM, zero where there is no trigram
+        const uint32_t o = q.k * kLinksBlock + fpos, L = q.L;
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;
-        const uint4 w = *reinterpret_cast<const uint4*>(hbuf32 + (k & 1u) * kLinksBlock + fpos);   // 32-bit slots, the link in each one's low half
+        uint4 w = *reinterpret_cast<const uint4*>(hbuf32 + (q.g & 1u) * kLinksBlock + fpos);   // what each exchange returned: (epoch << 16) | predecessor
+        const uint32_t ep = q.j + 1u;
+        w.x = (w.x >> 16) == ep ? w.x : 0u; w.y = (w.y >> 16) == ep ? w.y : 0u;                    // another chunk's leftovers: NIL
+        w.z = (w.z >> 16) == ep ? w.z : 0u; w.w = (w.w >> 16) == ep ? w.w : 0u;
         uint2 v = make_uint2((w.x & 0xffffu) | w.y << 16, (w.z & 0xffffu) | w.w << 16);
         if (n_ok < kPer) {                             // rare: the chunk's last positions
             if (n_ok == 0u) v.x = 0; else if (n_ok == 1u) v.x &= 0xffffu;
             if (n_ok <= 2u) v.y = 0; else if (n_ok == 3u) v.y &= 0xffffu;
         }
-        *reinterpret_cast<uint2*>(lk + o) = v;
+        *reinterpret_cast<uint2*>(q.lk + o) = v;
         linked += (uint32_t)((v.x & 0xffffu) != 0) + (uint32_t)((v.x >> 16) != 0) + (uint32_t)((v.y & 0xffffu) != 0) + (uint32_t)((v.y >> 16) != 0);
     };
 
@@ -175,11 +199,11 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     const uint32_t head_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(head));   // LDS byte addresses
     const uint32_t hbuf_a = head_a + kHeadBytes + 16u;
     // one exchange per step (see the kernel's header)
-    auto insert_block = [&](uint32_t k) {
+    auto insert_block = [&](uint32_t k, uint32_t L, uint32_t tag /* epoch << 16 */, uint32_t parity) {
         const uint32_t first = k * kLinksBlock;
         const uint32_t n_steps = __builtin_amdgcn_readfirstlane((min(L, first + kLinksBlock) - first + 63u) / 64u);      // >= 1
-        uint32_t base = hbuf_a + 4u * ((k & 1u) * kLinksBlock + lane);                    // this lane's buffer entry of step s
-        uint32_t p0 = first + lane;
+        uint32_t base = hbuf_a + 4u * (parity * kLinksBlock + lane);                      // this lane's buffer entry of step s
+        uint32_t p0 = tag + first + lane;                                                 // what a bucket holds: epoch and position
         auto step_now = [&](uint32_t slot, uint32_t p) {                                  // one step, start to finish
             uint32_t a, prev;
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(slot) : "memory");
@@ -389,56 +413,73 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     // block k + 2 asked for one hand-over ahead of their use every hand-over waited for them (4.8 of the kernel's 5.4 ms
     // with the inserter switched off).  Three register sets take turns, so a request has three hand-overs to land.
     using Slot0 = std::integral_constant<uint32_t, 0>; using Slot1 = std::integral_constant<uint32_t, 1>; using Slot2 = std::integral_constant<uint32_t, 2>;
-    if (wave >= 1) {                                // the first requests go out before the table is cleared: one round trip less per chunk
-        load_block(0, Slot0{});
-        load_block(1, Slot1{});
-        load_block(2, Slot2{});
+    Cursor ld{blockIdx.x, 0, 0, 0, 0, 0, nullptr, nullptr}, hs = ld, fl = ld;   // feeders: input requests, bucket addresses, links out
+    if (wave >= 1) {                                // the first requests go out before the table is cleared: one round trip less
+        enter(ld); hs = ld; fl = ld;
+        load_block(ld, Slot0{}); advance(ld);
+        load_block(ld, Slot1{}); advance(ld);
+        load_block(ld, Slot2{}); advance(ld);
         pad_stores(3u * kStoreOps);                 // (the counted wait assumes two earlier trips)
     }
     {
         uint4* h4 = reinterpret_cast<uint4*>(head);
-        for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < (kHeadBytes + 16u) / 16u; i += kLinksThreads) h4[i] = make_uint4(0, 0, 0, 0);   // epoch 0: nobody's
     }
     if (wave >= 1) {
-        hash_block(0, Slot0{});
-        load_block(3, Slot0{});
+        hash_block(hs, Slot0{}); advance(hs);
+        load_block(ld, Slot0{}); advance(ld);
     }
     __syncthreads();
-    // One hand-over: the inserter links block k; the feeders write out block k - 1, hash block k + 1 (register set NEXT_) and
-    // ask for block k + 4 into the set that has just become free.  It concerns LDS only: __syncthreads() would also drain
-    // the feeders' input loads and link stores.  The two roles run their own loops, both to the next multiple of three
-    // hand-overs (blocks that do not exist hash to the no-trigram bucket and are never inserted or written out).
+    // One hand-over: the inserter links block g; the feeders write out block g - 1, hash block g + 1 (register set NEXT_) and
+    // ask for block g + 4 into the set that has just become free.  It concerns LDS only: __syncthreads() would also drain
+    // the feeders' input loads and link stores.  The two roles run their own loops over the same number of hand-overs.
 #define ZWZ_LINKS_HANDOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    const uint32_t n_trips = (n_blocks + 2u) / 3u * 3u;
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);              // the inserter shares its SIMD with two feeder waves and is the critical path
-        for (uint32_t k = 0; k < n_trips; k++) {
-            if (k < n_blocks) {
-                insert_block(k);
+        uint32_t g = 0;
+        for (uint32_t c = blockIdx.x, j = 0; c < n; c += G, j++) {
+            const uint32_t L = in_len[c];
+            const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
+            for (uint32_t k = 0; k < n_blocks; k++, g++) {
+                insert_block(k, L, (j + 1u) << 16, g & 1u);
+                ZWZ_LINKS_HANDOVER();
             }
-            ZWZ_LINKS_HANDOVER();
         }
+        for (; g % 3u; g++) ZWZ_LINKS_HANDOVER();   // the feeders go three hand-overs a turn
     } else {
-#define ZWZ_LINKS_TRIP(K_, NEXT_)                                                                  \
-        if ((K_) == 0u) pad_stores(kStoreOps); else if ((K_) <= n_blocks) flush_block((K_) - 1u);  \
-        hash_block((K_) + 1u, NEXT_{});                                                            \
-        load_block((K_) + 4u, NEXT_{});                                                            \
+        auto chunk_done = [&](const Cursor& q) {    // the feeder waves add up a chunk's linked positions: lz_match picks its work order by it
+            for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
+            if (lane == 0 && linked) atomicAdd(&link_stat[q.c], linked);
+            linked = 0;
+        };
+        bool first_trip = true;                     // fl sits on the block the inserter has just finished, except before the first trip
+        bool more = fl.c < n;                       // the block the inserter takes up at this hand-over exists
+#define ZWZ_LINKS_TRIP(NEXT_)                                                                      \
+        if (first_trip) { pad_stores(kStoreOps); first_trip = false; }                             \
+        else if (fl.c < n) {                                                                       \
+            flush_block(fl);                                                                       \
+            if (fl.k + 1u >= fl.n_blocks) chunk_done(fl);                                          \
+            advance(fl);                                                                           \
+        } else pad_stores(kStoreOps);                                                              \
+        more = hs.c < n;                            /* the next hand-over's block */               \
+        hash_block(hs, NEXT_{}); advance(hs);                                                      \
+        load_block(ld, NEXT_{}); advance(ld);                                                      \
         ZWZ_LINKS_HANDOVER();
-        for (uint32_t k = 0; k < n_trips; k += 3u) {
-            ZWZ_LINKS_TRIP(k, Slot1)
-            ZWZ_LINKS_TRIP(k + 1u, Slot2)
-            ZWZ_LINKS_TRIP(k + 2u, Slot0)
+        while (more) {                              // three hand-overs a turn, as the inserter counts them; the last of a stream may be idle
+            ZWZ_LINKS_TRIP(Slot1)
+            ZWZ_LINKS_TRIP(Slot2)
+            ZWZ_LINKS_TRIP(Slot0)
         }
 #undef ZWZ_LINKS_TRIP
-    }
-#undef ZWZ_LINKS_HANDOVER
-    if (wave >= 1) {
-        if (n_trips == n_blocks) flush_block(n_blocks - 1);   // (else the trip after the last block has written it out)
-        for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
-        if (lane == 0) {                                // lz_match picks its work order by it
-            atomicAdd(&link_stat[chunk], linked);
+        // The last requests (for blocks past the stream's end) are still in flight, into registers the compiler considers dead from
+        // here on: they must land before anything else is computed in them (the flush below built a store's data, or address, in one).
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_ring[0].c), "+v"(in_ring[0].t), "+v"(in_ring[1].c), "+v"(in_ring[1].t), "+v"(in_ring[2].c), "+v"(in_ring[2].t) :: "memory");
+        if (!first_trip && fl.c < n) {              // the stream's last block, if its length is a multiple of three (fl is one behind)
+            flush_block(fl);
+            chunk_done(fl);
         }
     }
+#undef ZWZ_LINKS_HANDOVER
 }
 
 // Workgroup copy of n 16-byte vectors global -> LDS with eight loads in flight per thread.
@@ -2210,11 +2251,26 @@ hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
     return e;
 }
 
+// lz_links: a workgroup per CU (a.cu_count; the self-test passes fewer to make every workgroup cross chunk boundaries), chunks
+// strided over them; an epoch is 16 bits, so a launch covers at most 65 535 chunks per workgroup
+static hipError_t launch_links(const DeflateArgs& a, hipStream_t s) {
+    ZWZ_TRY(hipMemsetAsync(a.link_stat, 0, (size_t)a.n * sizeof(uint32_t), s));
+    const uint32_t cus = a.cu_count ? a.cu_count : 256u;
+    for (uint32_t done = 0; done < a.n;) {
+        const uint32_t left = a.n - done, G = left < cus ? left : cus;
+        const uint64_t cap = 65535ull * G;
+        const uint32_t m = left < cap ? left : (uint32_t)cap;
+        hipLaunchKernelGGL(lz_links_kernel, dim3(G), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off + done, a.in_len + done,
+                           a.links + (size_t)done * kLinkStride, a.link_stat + done, m);
+        done += m;
+    }
+    return hipGetLastError();
+}
+
 // lz_links alone over a batch (zwz_ctx_create's known-answer test of the hand-scheduled kernel)
 hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
-    return hipGetLastError();
+    return launch_links(a, s);
 }
 
 hipError_t configure_kernels() {
@@ -2229,7 +2285,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (a.n == 0) return hipSuccess;
     ZWZ_TRY(hipMemsetAsync(a.tickets, 0, kTicketBytes, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lz_links_kernel, dim3(a.n), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat);
+    ZWZ_TRY(launch_links(a, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat);
