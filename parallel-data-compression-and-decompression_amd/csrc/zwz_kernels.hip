@@ -1835,8 +1835,6 @@ struct InflateWaveMem {
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
     __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
-    uint16_t jump[64 * kWinSlots + 8];       // window offset -> offset of the symbol after the one starting there (pointer doubling)
-    uint32_t flag[64 * kWinSlots / 4];       // one byte per window offset: reached from offset 0
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
@@ -1967,44 +1965,34 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     inf[r] = kind | (nb << 3); val[r] = v;
                 }
                 // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
-                // A scalar loop hopping through it with v_readlane took ~50 SALU instructions a symbol, and a CU has ONE
-                // scalar issue slot a cycle for its 20 waves: 70 % of this kernel's time on text.  So the orbit is marked
-                // by pointer doubling over the 256 offsets (<= 8 rounds, usually 5), ranks and output positions come from
-                // ballots and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols,
-                // end of block, an error, a code for the sequential decoder) -- the same decisions in the same order
-                // of precedence as the loop they replace.
+                // It is followed by a scalar loop that does nothing but mark: one v_readlane (the next offset, out of the
+                // lane that decoded this one), one bit set in a scalar mask, a compare and a branch per symbol -- ~18 symbols a
+                // round on text.  (History: a scalar loop that also classified and stored each symbol cost ~50 scalar
+                // instructions a symbol, and a CU has one scalar issue slot a cycle for its 20 waves; pointer doubling over the
+                // 256 offsets in vector code -- 5-6 rounds of LDS gathers and ballots, ~120 vector instructions a round -- took its
+                // place, and the vector unit became what the kernel runs out of.)  Ranks and output positions come from ballots
+                // and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols, end of block, an
+                // error, a code for the sequential decoder).
                 constexpr uint32_t kSink = 64u * kWinSlots;
                 uint32_t jr[kWinSlots];
-                uint8_t* flag8 = reinterpret_cast<uint8_t*>(m.flag);
-                m.flag[lane] = lane == 0 ? 1u : 0u;                       // offset 0 is reached by definition
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t adv = r * 64u + lane + (inf[r] >> 3);
-                    jr[r] = (inf[r] & 7u) <= kMatch ? (adv < kSink ? adv : kSink) : kSink;      // only literals and matches lead on
-                    m.jump[r * 64u + lane] = (uint16_t)jr[r];
+                    const uint32_t nbits = inf[r] >> 3, adv = r * 64u + lane + nbits;
+                    jr[r] = (((inf[r] & 7u) <= kMatch) & (nbits != 0u)) ? (adv < kSink ? adv : kSink) : kSink;   // only literals and matches lead on (and strictly forward)
                 }
-                if (lane == 0) m.jump[kSink] = (uint16_t)kSink;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint64_t M[kWinSlots] = {1ull, 0ull, 0ull, 0ull};           // reached offsets, slot by slot (wave-uniform)
-                for (uint32_t round = 0; round < 8; round++) {
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++)                 // everything reached so far marks what lies 2^round symbols on
-                        if (((M[r] >> lane) & 1ull) && jr[r] < kSink) flag8[jr[r]] = 1;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    bool grown = false;
+                uint64_t M[kWinSlots];                                        // reached offsets, slot by slot (wave-uniform)
+                {
+                    uint32_t at = 0;                                          // wave-uniform: the orbit's current offset
 #pragma unroll
                     for (uint32_t r = 0; r < kWinSlots; r++) {
-                        const uint64_t now = __ballot(flag8[r * 64u + lane] != 0);
-                        grown = grown || now != M[r];
-                        M[r] = now;
+                        uint64_t mk = 0;
+                        while (at < 64u * (r + 1u)) {                         // (at >= 64 r: offsets only grow)
+                            const uint32_t l = at - 64u * r;
+                            mk |= 1ull << l;
+                            at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l);
+                        }
+                        M[r] = mk;
                     }
-                    if (!grown) break;
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) jr[r] = m.jump[jr[r]];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) m.jump[r * 64u + lane] = (uint16_t)jr[r];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
                 // Ranks (symbol index in the batch) and output positions of the reached offsets, in window order; the first
                 // reached offset at which the batch must end decides how the round ends.  Symbols go into the batch arrays
