@@ -1834,6 +1834,7 @@ struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
+    uint2 sym[kBatch + 1];                    // a round's symbols in orbit order: (kind << 25 | value, bits << 9 | window offset)
     __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
@@ -1994,53 +1995,59 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                         M[r] = mk;
                     }
                 }
-                // Ranks (symbol index in the batch) and output positions of the reached offsets, in window order; the first
-                // reached offset at which the batch must end decides how the round ends.  Symbols go into the batch arrays
-                // as they are ranked; the entries from the end of the batch on are blanked afterwards.
-                m.pos[lane] = 0xffffffffu;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint32_t base = 0, carry = 0, cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
-                bool ended = false;
+                // The reached offsets hand their symbols to the batch in orbit order: a marked (slot, lane) writes (kind, value)
+                // and (offset, bits) to entry `rank` of an LDS array -- and then ONE pass with lane i on symbol i does what
+                // used to be done slot by slot over the sparse window (four scans, four sets of tests, ~190 vector instructions
+                // a round): output positions from one scan, the first symbol at which the batch must end (an end of block, a
+                // code for the sequential decoder, an error, output that would not fit) from one ballot.  Entry kBatch is the
+                // symbol a full batch leaves for the next round.
+                uint32_t nsym = 0;
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
-                    // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow,
-                    // ~100 scalar instructions per slot -- and the scalar unit is what this kernel runs out of)
-                    const uint32_t kd = inf[r] & 7u;
-                    const uint32_t mk = (uint32_t)(M[r] >> lane) & 1u;
-                    const uint32_t rank = base + rank_in(M[r]);
-                    const uint32_t is_lit = (uint32_t)(kd == kLit), is_match = (uint32_t)(kd == kMatch), mlen = val[r] >> 16;
-                    const uint32_t ol = mk * (is_lit + is_match * mlen);
-                    const uint32_t sc = wave_scan_incl(ol);
-                    const uint32_t pos = opos_u + carry + sc - ol;
-                    const uint32_t ends = mk & ((uint32_t)(rank >= kBatch) | (uint32_t)(kd >= kEob) | (is_lit & (uint32_t)(pos >= kChunk)) |
-                                                (is_match & ((uint32_t)((val[r] & 0xffffu) > pos) | (uint32_t)(pos + mlen > kChunk))));
-                    if (mk & (ends ^ 1u)) { m.batch[rank] = val[r]; m.pos[rank] = pos; }      // not at an end implies rank < kBatch
-                    const uint64_t C = __ballot(ends != 0);
-                    if (!ended && C) {                                     // wave-uniform: the round ends at this offset
-                        ended = true;
-                        const uint32_t lc = (uint32_t)__builtin_ctzll(C);
-                        const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_rank = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)lc);
-                        const uint32_t c_val = (uint32_t)__builtin_amdgcn_readlane((int)val[r], (int)lc);
-                        opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
-                        cur = r * 64u + lc;
-                        k = c_rank < kBatch ? c_rank : kBatch;
-                        if (c_rank >= kBatch) { /* batch full: the next round starts at this symbol */ }
-                        else if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
-                        else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
-                        else if (c_kind == kEob) { cur += (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)lc); stop = kEob; }
-                        else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
-                    }
-                    if (!ended && M[r]) {                                  // so far plain symbols: the chain leaves the window behind the last of them
-                        const uint32_t ll = 63u - (uint32_t)__builtin_clzll(M[r]);
-                        cur = r * 64u + ll + (uint32_t)__builtin_amdgcn_readlane((int)(inf[r] >> 3), (int)ll);
-                    }
-                    base += (uint32_t)__popcll(M[r]);
-                    carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                    const uint32_t rank = nsym + rank_in(M[r]);
+                    if (((M[r] >> lane) & 1ull) && rank <= kBatch)
+                        m.sym[rank] = make_uint2(val[r] | (inf[r] & 7u) << 25, (r * 64u + lane) | (inf[r] >> 3) << 9);   // value < 2^25: length < 512, distance <= 32768
+                    nsym += (uint32_t)__popcll(M[r]);
                 }
-                if (!ended) { k = base; opos_new = opos_u + carry; }
-                bp += cur;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (lane >= k) m.pos[lane] = 0xffffffffu;                  // symbols ranked behind the end of the batch do not belong to it
+                uint32_t cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
+                {
+                    // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow)
+                    const uint32_t have = (uint32_t)(lane < nsym);             // nsym >= 1: offset 0 is always reached
+                    const uint2 sy = m.sym[lane];                              // (stale beyond nsym: masked by `have`)
+                    const uint32_t kd = sy.x >> 25, v = sy.x & 0x1ffffffu;
+                    const uint32_t is_lit = have & (uint32_t)(kd == kLit), is_match = have & (uint32_t)(kd == kMatch), mlen = v >> 16;
+                    const uint32_t ol = is_lit + is_match * mlen;
+                    const uint32_t sc = wave_scan_incl(ol);
+                    const uint32_t pos = opos_u + sc - ol;
+                    const uint32_t ends = have & ((uint32_t)(kd >= kEob) | (is_lit & (uint32_t)(pos >= kChunk)) |
+                                                  (is_match & ((uint32_t)((v & 0xffffu) > pos) | (uint32_t)(pos + mlen > kChunk))));
+                    const uint64_t C = __ballot(ends != 0);
+                    if (C) {                                               // wave-uniform: the round ends at this symbol
+                        const uint32_t lc = (uint32_t)__builtin_ctzll(C);
+                        const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_val = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lc);
+                        const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)lc);
+                        opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
+                        cur = c_off & 0x1ffu;
+                        k = lc;
+                        if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
+                        else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
+                        else if (c_kind == kEob) { cur += c_off >> 9; stop = kEob; }
+                        else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
+                    } else if (nsym > kBatch) {                            // batch full: the next round starts at symbol kBatch
+                        k = kBatch;
+                        cur = m.sym[kBatch].y & 0x1ffu;
+                        opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                    } else {                                               // plain symbols all the way: the chain leaves the window behind the last of them
+                        k = nsym;
+                        const uint32_t l_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)(nsym - 1u));
+                        cur = (l_off & 0x1ffu) + (l_off >> 9);
+                        opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                    }
+                    m.batch[lane] = v;
+                    m.pos[lane] = lane < k ? pos : 0xffffffffu;            // symbols from the end of the batch on do not belong to it
+                }
+                bp += cur;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // The wave moves the bytes of this batch, one output byte per lane per trip: find the
                 // symbol that produces the byte (binary search over the batch's start offsets), follow
