@@ -1816,7 +1816,8 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
 // coalesced): a round consumes < 1 KiB, so topping the ring up to pos + 1 KiB before every round keeps the
 // decoders off global memory entirely.
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
-constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per round: a 256-bit window
+constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
+constexpr uint32_t kWinParts = 2;          // windows a round may look at
 
 constexpr uint32_t kOwnCap = 1024;         // batch bytes the per-byte owner map covers (a batch is <= 64 symbols: ~300 bytes on text)
 
@@ -1834,7 +1835,7 @@ struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
-    uint2 sym[kBatch + 1];                    // a round's symbols in orbit order: (kind << 25 | value, bits << 9 | window offset)
+    uint2 sym[kBatch + 1];                    // a round's symbols in orbit order: (kind << 25 | value, bits << 10 | offset from the round's first bit)
     __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
@@ -1926,10 +1927,18 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             uint32_t block_done = 0, stop_status = kInfRunning;
             while (!block_done) {
                 top_up(bp >> 3);
+                // A round looks at up to kWinParts windows of 256 bits one after the other -- decode, follow the orbit, hand the
+                // symbols to the batch -- and then does everything that costs per round (output positions, end-of-batch tests,
+                // owner map, copy) once for what they yielded together: ~36 symbols on text, against a batch of 64.
+                uint32_t nsym = 0;                                            // symbols handed to the batch (wave-uniform)
+                uint32_t at = 0;                                              // wave-uniform: the orbit's current offset from bp; kOrbitEnd once it has stopped
+                constexpr uint32_t kOrbitEnd = 0xffffu;
+#pragma unroll 1
+              for (uint32_t wb = 0; wb < 256u * kWinParts; wb += 256u) {      // wb: this window's first offset
                 uint32_t inf[kWinSlots], val[kWinSlots];
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t a = bp + r * 64u + lane;
+                    const uint32_t a = bp + wb + r * 64u + lane;
                     const int32_t avail = (int32_t)total_bits - (int32_t)a;
                     const uint32_t byte = (a >> 3) & (kInfRing - 1u);
                     const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
@@ -1974,26 +1983,22 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 // place, and the vector unit became what the kernel runs out of.)  Ranks and output positions come from ballots
                 // and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols, end of block, an
                 // error, a code for the sequential decoder).
-                constexpr uint32_t kSink = 64u * kWinSlots;
                 uint32_t jr[kWinSlots];
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t nbits = inf[r] >> 3, adv = r * 64u + lane + nbits;
-                    jr[r] = (((inf[r] & 7u) <= kMatch) & (nbits != 0u)) ? (adv < kSink ? adv : kSink) : kSink;   // only literals and matches lead on (and strictly forward)
+                    const uint32_t nbits = inf[r] >> 3;
+                    jr[r] = (((inf[r] & 7u) <= kMatch) & (nbits != 0u)) ? wb + r * 64u + lane + nbits : kOrbitEnd;   // only literals and matches lead on (and strictly forward)
                 }
                 uint64_t M[kWinSlots];                                        // reached offsets, slot by slot (wave-uniform)
-                {
-                    uint32_t at = 0;                                          // wave-uniform: the orbit's current offset
 #pragma unroll
-                    for (uint32_t r = 0; r < kWinSlots; r++) {
-                        uint64_t mk = 0;
-                        while (at < 64u * (r + 1u)) {                         // (at >= 64 r: offsets only grow)
-                            const uint32_t l = at - 64u * r;
-                            mk |= 1ull << l;
-                            at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l);
-                        }
-                        M[r] = mk;
+                for (uint32_t r = 0; r < kWinSlots; r++) {
+                    uint64_t mk = 0;
+                    while (at < wb + 64u * (r + 1u)) {                        // (at >= wb + 64 r: offsets only grow)
+                        const uint32_t l = at - wb - 64u * r;
+                        mk |= 1ull << l;
+                        at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l);
                     }
+                    M[r] = mk;
                 }
                 // The reached offsets hand their symbols to the batch in orbit order: a marked (slot, lane) writes (kind, value)
                 // and (offset, bits) to entry `rank` of an LDS array -- and then ONE pass with lane i on symbol i does what
@@ -2001,14 +2006,15 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 // a round): output positions from one scan, the first symbol at which the batch must end (an end of block, a
                 // code for the sequential decoder, an error, output that would not fit) from one ballot.  Entry kBatch is the
                 // symbol a full batch leaves for the next round.
-                uint32_t nsym = 0;
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
                     const uint32_t rank = nsym + rank_in(M[r]);
                     if (((M[r] >> lane) & 1ull) && rank <= kBatch)
-                        m.sym[rank] = make_uint2(val[r] | (inf[r] & 7u) << 25, (r * 64u + lane) | (inf[r] >> 3) << 9);   // value < 2^25: length < 512, distance <= 32768
+                        m.sym[rank] = make_uint2(val[r] | (inf[r] & 7u) << 25, (wb + r * 64u + lane) | (inf[r] >> 3) << 10);   // value < 2^25: length < 512, distance <= 32768
                     nsym += (uint32_t)__popcll(M[r]);
                 }
+                if (at >= kOrbitEnd || nsym > kBatch) break;                  // the orbit has stopped, or the batch is full
+              }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 uint32_t cur = 0, k = 0, stop = 0xffu, opos_new = opos_u;
                 {
@@ -2028,20 +2034,20 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                         const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_val = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lc);
                         const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)lc);
                         opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
-                        cur = c_off & 0x1ffu;
+                        cur = c_off & 0x3ffu;
                         k = lc;
                         if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
                         else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
-                        else if (c_kind == kEob) { cur += c_off >> 9; stop = kEob; }
+                        else if (c_kind == kEob) { cur += c_off >> 10; stop = kEob; }
                         else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
                     } else if (nsym > kBatch) {                            // batch full: the next round starts at symbol kBatch
                         k = kBatch;
-                        cur = m.sym[kBatch].y & 0x1ffu;
+                        cur = m.sym[kBatch].y & 0x3ffu;
                         opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
                     } else {                                               // plain symbols all the way: the chain leaves the window behind the last of them
                         k = nsym;
                         const uint32_t l_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)(nsym - 1u));
-                        cur = (l_off & 0x1ffu) + (l_off >> 9);
+                        cur = (l_off & 0x3ffu) + (l_off >> 10);
                         opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
                     }
                     m.batch[lane] = v;
