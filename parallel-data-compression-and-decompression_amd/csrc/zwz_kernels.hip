@@ -621,6 +621,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // 2 KiB: has128 bits of a tile
     uint16_t* s_cnt = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes + kMatchLinkBytes + 2048);   // 4 KiB: bucket counts
     __shared__ uint32_t s_wtot[kMatchThreads / 64];
+    __shared__ uint32_t s_grp;
     uint16_t* perm = perms + (size_t)chunk * kTile;
     uint4* sd4 = reinterpret_cast<uint4*>(sdata);
     uint4* sl4 = reinterpret_cast<uint4*>(slink);
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 uint32_t wbase = 0, total = 0;
                 for (uint32_t i = 0; i < kMatchThreads / 64; i++) { const uint32_t w = s_wtot[i]; wbase += i < wave ? w : 0u; total += w; }
                 nlist = __builtin_amdgcn_readfirstlane(total);
+                if (tid == 0) s_grp = (total + 63u) >> 6;                    // groups of the work list still to be taken (the walk below)
                 const uint32_t ex = wbase + incl - own;
                 *reinterpret_cast<uint2*>(s_cnt + 4 * tid) = make_uint2(ex | (ex + a) << 16, (ex + a + b) | (ex + a + b + c) << 16);
             }
@@ -781,9 +783,14 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             }
         };
         if (sorted_order) {
-            for (uint32_t kk = 0; kk < 16u; kk++) {
-                const uint32_t idx = tid + kk * kMatchThreads;
-                if (__ballot(idx < nlist) == 0) break;
+            // Waves take groups of 64 list entries off a counter, longest predicted chains first: dealt out in a fixed order
+            // (16 groups a wave) the waves finished up to a fifth of the walk apart -- a SIMD favours its oldest wave.
+            for (;;) {
+                uint32_t g = 0;
+                if (lane == 0) g = atomicSub(&s_grp, 1u);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if ((int32_t)g <= 0) break;
+                const uint32_t idx = (g - 1u) * 64u + lane;
                 search_and_store(idx < nlist ? ts + (uint32_t)perm[idx] : ts, idx < nlist);
             }
         } else {
