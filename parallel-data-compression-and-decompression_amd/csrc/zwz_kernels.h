@@ -23,7 +23,8 @@ constexpr uint32_t kParseThreads = 256;                          // 4 chunks per
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
-constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + kMaskWords * 8 + kMaskWords * 2 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 80496: two workgroups per CU
+constexpr uint32_t kEncQueue = 128;                               // entries of a wave's queue of symbol starts (a power of two >= 127)
+constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + (kEncodeThreads / 64) * kEncQueue * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 78448: two workgroups per CU
 constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
 constexpr int kNumDeflateStages = 6;
 

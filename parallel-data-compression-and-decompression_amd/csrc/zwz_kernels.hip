@@ -1625,9 +1625,8 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     // Persistent (two workgroups a CU by LDS): the chunks encode_stored_kernel left on the list, handed out by a ticket counter.
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
-    uint64_t* s_sym = reinterpret_cast<uint64_t*>(smem + kOutWords * 4);          // kMaskWords
-    uint16_t* s_rank = reinterpret_cast<uint16_t*>(s_sym + kMaskWords);           // kMaskWords (symbols before word w < 65536)
-    uint16_t* s_lcode = s_rank + kMaskWords;                                      // kMaxBlocks * 288
+    uint32_t* s_queue = reinterpret_cast<uint32_t*>(smem + kOutWords * 4);        // kEncQueue entries per wave (8 KiB): symbol starts waiting for a full trip
+    uint16_t* s_lcode = reinterpret_cast<uint16_t*>(s_queue + (kEncodeThreads / 64) * kEncQueue);   // kMaxBlocks * 288
     uint16_t* s_dcode = s_lcode + kMaxBlocks * 288;                               // kMaxBlocks * 32
     uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
     uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
@@ -1655,20 +1654,17 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
     for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
-    // symbol ranks again (cheaper to recompute than to round-trip through HBM), and match ranks: thread t holds mask
-    // word t, wave w's words are exactly its 4096-position segment below
+    // match ranks (cheaper to recompute than to round-trip through HBM): thread t holds mask words t of both masks, wave w's
+    // words are exactly its 4096-position segment below
     const uint64_t mst_l = tid < nwords ? gmst[tid] : 0ull;   // kEncodeThreads == kMaskWords
+    const uint64_t sym_l = tid < nwords ? gsym[tid] : 0ull;
     uint32_t mprefix;                                         // matches before this thread's word = its first index into `chosen`
     {
-        uint64_t w = tid < nwords ? gsym[tid] : 0ull;
-        s_sym[tid] = w;
-        const uint32_t cnt = (uint32_t)__popcll(w), incl = wave_scan_incl(cnt);
         const uint32_t mcnt = (uint32_t)__popcll(mst_l), mincl = wave_scan_incl(mcnt);
-        if (lane_id() == 63) { s_wsum[tid >> 6] = incl; s_msum[tid >> 6] = mincl; }
+        if (lane_id() == 63) s_msum[tid >> 6] = mincl;
         __syncthreads();
-        uint32_t wbase = 0, mbase = 0;
-        for (uint32_t i = 0; i < (tid >> 6); i++) { wbase += s_wsum[i]; mbase += s_msum[i]; }
-        s_rank[tid] = (uint16_t)(wbase + incl - cnt);
+        uint32_t mbase = 0;
+        for (uint32_t i = 0; i < (tid >> 6); i++) mbase += s_msum[i];
         mprefix = mbase + mincl - mcnt;
     }
     for (uint32_t b = 0; b < ci.n_blocks; b++) {
@@ -1724,68 +1720,104 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
     uint8_t* s_out8 = reinterpret_cast<uint8_t*>(s_out);
     {
+        // Adler-32 partials: a = 1 + sum d_i, b = L + sum (L - i) d_i; 16 dwords per thread, v_dot4 (the slot is readable to
+        // L rounded up to 16, what lies past L is masked)
+        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
+#pragma unroll 1
+        for (uint32_t u0 = 0; u0 < 16u; u0 += 4u) {                       // four loads in flight (sixteen pushed this kernel's 64 registers into scratch)
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = (tid + (u0 + u) * kEncodeThreads) * 4u; w[u] = i < L ? d32[i >> 2] : 0u; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t i = (tid + (u0 + u) * kEncodeThreads) * 4u;
+                uint32_t x = w[u];
+                if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
+                const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
+                a_sum += sum;
+                b_sum += (i < L ? (L - i) * sum - ramp : 0u);    // < 2^27 per dword
+            }
+        }
+        // stored blocks among Huffman ones (rare): their bytes go straight into the stream
+        for (uint32_t b = 0; b < ci.n_blocks; b++) {
+            if (s_blk[b].type != kStored) continue;
+            const uint32_t st0 = s_blk[b].start, len = s_blk[b].end - st0, ob0 = s_blk[b].data_byte;
+            for (uint32_t i = tid; i < len; i += kEncodeThreads) if (ob0 + i < kOutWords * 4) s_out8[ob0 + i] = data[st0 + i];
+        }
+    }
+    {
         // Symbols.  Wave w owns the contiguous positions [4096 w, 4096 w + 4096): a first pass adds up
         // its code lengths, one barrier turns the 16 wave totals into start offsets, and the second
         // pass packs bits with wave-local scans only (a barrier per 1024 positions kept the single
         // resident workgroup of a CU waiting: 30 ms for 50k text chunks).
+        // Both passes work on symbol STARTS, 64 to a trip: only three positions in eight start a symbol on text, and walking the
+        // positions cost ~115 vector instructions per 64 of them in each pass on a kernel the vector unit bounds.  The segment's
+        // 64 words of both masks (and the match count in front of each) sit one per lane and are handed out by v_readlane; a
+        // word's symbol starts are appended to the wave's queue in LDS -- position, index of the chosen record, match flag --
+        // and whenever 64 are waiting they are taken as a trip, whose byte and chosen record are fetched while the trip before
+        // it is being worked on.  The records come from lz_parse's compact array (read from the position-indexed one, every
+        // 64-byte line of its 512 KB held a match start and both passes fetched all of it: ~50 GB a pass on text).
         const uint32_t wave = tid >> 6, lane = lane_id();
         const uint32_t seg = wave * 4096u, seg_end = min(seg + 4096u, L);
         // blocks are contiguous position ranges: a position's block is the number of block starts at
         // or before it (holds for covered positions too: a block ends where its last symbol ends)
         const uint32_t b1 = ci.n_blocks > 1 ? s_blk[1].start : 0xffffffffu, b2 = ci.n_blocks > 2 ? s_blk[2].start : 0xffffffffu;
         const uint32_t b3 = ci.n_blocks > 3 ? s_blk[3].start : 0xffffffffu, b4 = ci.n_blocks > 4 ? s_blk[4].start : 0xffffffffu;
-        // The segment's 64 words of the match mask (and the match count in front of each) sit one per lane and are
-        // handed out by v_readlane; each trip's byte and chosen record are fetched one trip ahead.  The records come
-        // from lz_parse's compact array: read from the position-indexed one, every 64-byte line of its 512 KB
-        // held a match start and both passes fetched all of it (~50 GB a pass on text).
         auto word_of = [&](uint64_t v, uint32_t it) -> uint64_t {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, it);          // the builtin returns int:
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), it);  // widen only after the cast
             return (uint64_t)lo | ((uint64_t)hi << 32);
         };
-        auto fetch = [&](uint32_t it, uint32_t& byte, uint32_t& e) {   // trip `it` of this wave's segment
-            byte = 0; e = 0;
-            if (it >= 64u) return;                                     // wave-uniform
-            const uint64_t mw = word_of(mst_l, it);                    // readlane outside divergent code
-            const uint32_t mfirst = (uint32_t)__builtin_amdgcn_readlane((int)mprefix, it);
-            const uint32_t p = seg + (it << 6) + lane;
-            if (p < seg_end) {
-                byte = data[p];
-                if ((mw >> lane) & 1ull) e = chosen[mfirst + rank_in(mw)];   // dense: 4 bytes per match
-            }
-        };
         auto block_of = [&](uint32_t p) { return (uint32_t)(p >= b1) + (uint32_t)(p >= b2) + (uint32_t)(p >= b3) + (uint32_t)(p >= b4); };
         const uint32_t trips = (seg_end > seg ? seg_end - seg + 63u : 0u) >> 6;
-
-        uint32_t mine = 0, byte_n, e_n;
-        fetch(0, byte_n, e_n);
-        for (uint32_t it = 0; it < trips; it++) {
-            const uint32_t p = seg + (it << 6) + lane, byte = byte_n, e = e_n;
-            fetch(it + 1, byte_n, e_n);
-            if (p < seg_end && ((s_sym[p >> 6] >> lane) & 1ull)) {
-                const uint32_t blk = block_of(p);
-                if (s_blk[blk].type != kStored) mine += symbol_nbits(s_llen + blk * 288, s_dlen + blk * 32, e, byte);
+        uint32_t* queue = s_queue + wave * kEncQueue;
+        // entry: position | index into `chosen` << 16 | match flag << 31
+        auto for_each_trip = [&](auto&& work) {                            // work(entry, byte, record, live) for every trip of <= 64 symbol starts, in stream order
+            uint32_t head = 0, tail = 0;                                   // wave-uniform: queue[head, tail) is waiting
+            uint32_t p_ent = 0, p_byte = 0, p_rec = 0, p_n = 0;            // the trip whose operands are in flight
+            auto take = [&](uint32_t n) {                                  // fetch for n waiting entries, then work on the trip taken before
+                const uint32_t ent = queue[(head + lane) & (kEncQueue - 1u)];       // (lanes >= n: stale entries, masked by `live`)
+                const bool live = lane < n;
+                const uint32_t byte = live ? (uint32_t)data[ent & 0xffffu] : 0u;
+                const uint32_t rec = live && (ent >> 31) ? chosen[(ent >> 16) & 0x7fffu] : 0u;   // dense: 4 bytes per match
+                head += n;
+                if (p_n) work(p_ent, p_byte, p_rec, lane < p_n);
+                p_ent = ent; p_byte = byte; p_rec = rec; p_n = n;
+            };
+            for (uint32_t it = 0; it < trips; it++) {
+                const uint64_t sw = word_of(sym_l, it);                    // readlane outside divergent code
+                if (sw == 0) continue;                                     // wave-uniform
+                const uint64_t mw = word_of(mst_l, it);
+                const uint32_t mfirst = (uint32_t)__builtin_amdgcn_readlane((int)mprefix, it);
+                if ((sw >> lane) & 1ull) {
+                    const uint32_t is_m = (uint32_t)(mw >> lane) & 1u;
+                    queue[(tail + rank_in(sw)) & (kEncQueue - 1u)] = (seg + (it << 6) + lane) | (is_m ? 0x80000000u | (mfirst + rank_in(mw)) << 16 : 0u);
+                }
+                tail += (uint32_t)__popcll(sw);
+                while (tail - head >= 64u) take(64u);
             }
-        }
+            if (tail != head) take(tail - head);
+            if (p_n) work(p_ent, p_byte, p_rec, lane < p_n);
+        };
+
+        uint32_t mine = 0;
+        for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
+            if (live) {
+                const uint32_t blk = block_of(ent & 0xffffu);
+                if (s_blk[blk].type != kStored) mine += symbol_nbits(s_llen + blk * 288, s_dlen + blk * 32, rec, byte);
+            }
+        });
         for (uint32_t d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
         if (lane == 0) s_wsum[wave] = mine;
         __syncthreads();
         uint32_t running = 0;      // symbol bits emitted before this wave's segment (all Huffman blocks)
         for (uint32_t i = 0; i < wave; i++) running += s_wsum[i];
-        fetch(0, byte_n, e_n);
-        for (uint32_t it = 0; it < trips; it++) {
-            const uint32_t p = seg + (it << 6) + lane, byte = byte_n, e = e_n;
-            fetch(it + 1, byte_n, e_n);
+        for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
             uint64_t v = 0; uint32_t nb = 0, blk = 0;
-            if (p < seg_end) {
-                blk = block_of(p);
-                a_sum += byte; b_sum += (unsigned long long)(L - p) * byte;
-                if (s_blk[blk].type == kStored) {
-                    const uint32_t ob = s_blk[blk].data_byte + (p - s_blk[blk].start);
-                    if (ob < kOutWords * 4) s_out8[ob] = (uint8_t)byte;
-                } else if ((s_sym[p >> 6] >> lane) & 1ull) {
-                    symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, e, byte, v, nb);
-                }
+            if (live) {
+                blk = block_of(ent & 0xffffu);
+                if (s_blk[blk].type != kStored)
+                    symbol_bits(s_lcode + blk * 288, s_llen + blk * 288, s_dcode + blk * 32, s_dlen + blk * 32, rec, byte, v, nb);
             }
             const uint32_t incl = wave_scan_incl(nb);
             if (nb) {
@@ -1793,7 +1825,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
                 lds_or_bits(s_out, (uint64_t)eb.body_pos + (running + incl - nb - eb.sym_bits_before), v, nb);
             }
             running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
+        });
     }
 
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
