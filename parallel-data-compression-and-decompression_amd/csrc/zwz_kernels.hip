@@ -500,11 +500,10 @@ static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, 
 // The chain walk is the framework's hottest loop.  Written per lane it compiles to ~32 instructions
 // per candidate, a third of them exec-mask bookkeeping for the per-lane exits; a predicated C++
 // version fared no better (every wave-uniform test became a select-and-compare pair).  So the
-// common path -- fetch the candidate's filter word and its link, compare, advance -- is 21
-// instructions of inline asm in which no lane ever leaves the loop: the candidate counter is
-// wave-uniform (an SGPR), `alive` is an SGPR lane mask, a lane whose chain has ended keeps
-// re-reading its last candidate, and the loop falls out to C++ only when some live lane's filter
-// word matches (worth a full comparison), the counter reaches its bound, or no lane is left.
+// common path -- fetch the candidate's filter word and its link, compare, count, advance -- is a
+// loop of inline asm that runs with EXEC = the lanes still walking and keeps its lane sets in
+// SGPR masks; it falls out to C++ (the full comparison) only when enough lanes have a matching
+// filter word, or nobody walks any more (see "The walk" below).
 // (The filter word is two adjacent aligned dwords -- ONE ds_read2_b32 into a named register pair, which costs the LDS
 // ~13 cycles under random addresses against 2 x 10 for two ds_read_b32 (tools/exp/gather_rate.hip) -- and an alignbyte:
 // one unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.
@@ -535,65 +534,78 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
     const uint32_t link_a = (uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(link));
     const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a - 2u * org);
     uint32_t dbias = data_a - org + f_off;                         // filter word of candidate c: LDS byte cur + dbias
-    uint32_t n = 0;                                                // candidates examined: the same in every lane
-    // (a macro, not a lambda: with the SGPR operands captured by reference the backend fails with
-    // "illegal VGPR to SGPR copy")
-#define ZWZ_WALK(BOUND_)                                                                           \
-        for (;;) {                                                                                  \
-            uint64_t hit; uint32_t next, ta, tb, w0, tl;                                        \
-            asm volatile(                                                                           \
-                "1:\n\t"                                                                            \
-                "v_add_u32 %[a], %[cur], %[dbias]\n\t"                                              \
-                "v_and_b32 %[b], -4, %[a]\n\t"                                                      \
-                "ds_read2_b32 v[90:91], %[b] offset1:1\n\t"                                         \
-                "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"                                      \
-                "ds_read_u16 %[next], %[l]\n\t"                                                     \
-                "s_waitcnt lgkmcnt(1)\n\t"                                                          \
-                "v_alignbyte_b32 %[w0], v91, v90, %[a]\n\t"                                         \
-                "v_and_b32 %[w0], %[w0], %[fmask]\n\t"                                              \
-                "v_cmp_eq_u32 vcc, %[w0], %[scan]\n\t"                                              \
-                "s_and_b64 %[hit], vcc, %[alive]\n\t"                                               \
-                "s_cbranch_scc1 2f\n\t"                                                             \
-                "s_add_u32 %[n], %[n], 1\n\t"                                                       \
-                "s_waitcnt lgkmcnt(0)\n\t"                                                          \
-                "v_cmp_gt_u32 vcc, %[next], %[limit]\n\t"                                           \
-                "s_and_b64 %[alive], %[alive], vcc\n\t"                                             \
-                "v_cndmask_b32 %[cur], %[cur], %[next], %[alive]\n\t"                               \
-                "s_cbranch_scc0 2f\n\t"                                                             \
-                "s_cmp_lt_u32 %[n], %[bound]\n\t"                                                   \
-                "s_cbranch_scc1 1b\n\t"                                                             \
-                "2:\n\t"                                                                            \
-                "s_waitcnt lgkmcnt(0)"                                                              \
-                : [cur] "+v"(cur), [alive] "+s"(alive), [n] "+s"(n), [hit] "=&s"(hit), [next] "=&v"(next), [a] "=&v"(ta), [b] "=&v"(tb),\
-                  [w0] "=&v"(w0), [l] "=&v"(tl)                                                     \
-                : [dbias] "v"(dbias), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(BOUND_)\
-                : "vcc", "scc", "memory", "v90", "v91");                                            \
-            if (hit == 0) break;                                                                    \
-            if ((hit >> lane) & 1ull) {                                                             \
-                const uint32_t c_ = cur - org;                                                      \
-                uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;    \
-                asm volatile("" : "+v"(x0), "+v"(x1));   /* both words now: left alone, the second read is sunk behind a branch on the first */\
-                const uint32_t l0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, l1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3);\
-                uint32_t len = x0 ? l0 : x1 ? l1 : 8u;                                              \
-                if (len == 8u) len = match_len_from(data, c_, pp, 8u, max_len);                     \
-                len = len < max_len ? len : max_len;                                                \
-                if (len > best) {                                                                   \
-                    best = len; best_pos = cur;                                                     \
-                    if (len >= nice) next = 0;                                                      \
-                    else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a - org + f_off; }\
-                }                                                                                   \
-            }                                                                                       \
-            n++;                                                                                    \
-            alive &= __builtin_amdgcn_ballot_w64(next > limit);                                     \
-            if ((alive >> lane) & 1ull) cur = next;                                                 \
-            if (n >= BOUND_ || alive == 0) break;                                                   \
+    // The walk.  A lane examines its candidates at its own pace and count (n_l): lanes whose filter word matches are PARKED --
+    // they stop walking, candidate and link at hand -- and the full comparison is done for all parked lanes at once when
+    // kParkLanes of them are waiting or nobody walks any more.  (Leaving the loop for every single hit -- with a wave-wide
+    // candidate count that is what exactness seemed to ask for -- the divergent comparison ran once per 3.7 wave-steps on text for
+    // one or two lanes, ~1100 cycles each time: more than half of the walk.)  The loop runs with EXEC = the walking lanes,
+    // so parked and finished lanes cost the LDS nothing.  Per lane the sequence of candidates, the counts and every
+    // decision are lz_search's: 128 candidates at most, and zlib's short-chain answer (the best after 32, if a 33rd is
+    // in range) is taken lazily -- `best` only changes in the comparison, so the first comparison behind the 32nd candidate
+    // (or the end) still sees it.
+    constexpr uint32_t kParkLanes = 12;
+    uint32_t n_l = 0, nxt = cur;                                   // candidates examined by this lane; the link of `cur`
+    uint64_t walk = alive, park = 0;
+    // (one asm statement: with the SGPR operands captured by reference in a lambda the backend fails with "illegal VGPR to SGPR copy")
+    while (walk) {
+        uint64_t sv, cont; uint32_t ta, tb, w0, tl, cnt;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "1:\n\t"
+            "s_mov_b64 exec, %[walk]\n\t"
+            "v_add_u32 %[a], %[cur], %[dbias]\n\t"
+            "v_and_b32 %[b], -4, %[a]\n\t"
+            "ds_read2_b32 v[90:91], %[b] offset1:1\n\t"
+            "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"
+            "ds_read_u16 %[nxt], %[l]\n\t"
+            "v_add_u32 %[nl], 1, %[nl]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 %[w0], v91, v90, %[a]\n\t"
+            "v_and_b32 %[w0], %[w0], %[fmask]\n\t"
+            "v_cmp_eq_u32 vcc, %[w0], %[scan]\n\t"                 /* within EXEC: the walking lanes that hit */
+            "s_or_b64 %[park], %[park], vcc\n\t"
+            "s_andn2_b64 %[walk], %[walk], vcc\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_u32 vcc, %[nxt], %[limit]\n\t"               /* the chain goes on ... */
+            "v_cmp_gt_u32 %[cont], %[bound], %[nl]\n\t"            /* ... and the lane may follow it */
+            "s_and_b64 %[cont], %[cont], vcc\n\t"
+            "s_and_b64 %[walk], %[walk], %[cont]\n\t"
+            "v_cndmask_b32 %[cur], %[cur], %[nxt], %[walk]\n\t"    /* walking lanes step on; parked ones keep their candidate */
+            "s_bcnt1_i32_b64 %[cnt], %[park]\n\t"
+            "s_cmp_ge_u32 %[cnt], %[npark]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_cmp_lg_u64 %[walk], 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [cur] "+v"(cur), [nxt] "+v"(nxt), [nl] "+v"(n_l), [walk] "+s"(walk), [park] "+s"(park), [sv] "=&s"(sv), [cont] "=&s"(cont),
+              [cnt] "=&s"(cnt), [a] "=&v"(ta), [b] "=&v"(tb), [w0] "=&v"(w0), [l] "=&v"(tl)
+            : [dbias] "v"(dbias), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(kMaxChain),
+              [npark] "s"(kParkLanes)
+            : "vcc", "scc", "memory", "v90", "v91");
+        if (park == 0) break;                                      // nobody hit, nobody walks
+        bool resume = false;
+        if ((park >> lane) & 1ull) {                               // cur = the candidate whose filter word matched, nxt = its link, n_l counts it
+            if (n_l > kShortChain && snap == kNone) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;   // what zlib's short chain returned
+            const uint32_t c_ = cur - org;
+            uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;
+            asm volatile("" : "+v"(x0), "+v"(x1));   /* both words now: left alone, the second read is sunk behind a branch on the first */
+            const uint32_t l0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, l1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3);
+            uint32_t len = x0 ? l0 : x1 ? l1 : 8u;
+            if (len == 8u) len = match_len_from(data, c_, pp, 8u, max_len);
+            len = len < max_len ? len : max_len;
+            resume = nxt > limit && n_l < kMaxChain;
+            if (len > best) {
+                best = len; best_pos = cur;
+                if (len >= nice) resume = false;
+                else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a - org + f_off; }
+            }
+            cur = nxt;
         }
-    ZWZ_WALK(kShortChain)
-    if (n == kShortChain && alive != 0) {
-        if ((alive >> lane) & 1ull) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;   // what zlib's short chain returns
-        ZWZ_WALK(kMaxChain)
+        walk |= __builtin_amdgcn_ballot_w64(resume);
+        park = 0;
     }
-#undef ZWZ_WALK
+    if (n_l > kShortChain && snap == kNone) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;   // a 33rd candidate was examined: the short chain's answer
     e128 = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;
     e32 = snap != kNone ? snap : e128;
     // TOO_FAR: a minimum-length match further than 4096 back is dropped (deflate_slow)
