@@ -42,6 +42,28 @@ def test_deflate_matches_oracle(codec, oracle, kind):
         assert g == oracle.payload(c), (kind, len(c))
 
 
+def test_deflate_ragged_batch_crosses_chunk_boundaries(codec, oracle):
+    """One batch of 1500 chunks of every kind of length -- empty, shorter than a trigram, around lz_links' 2048-position
+    block, around the 16 Ki tile, full -- in a shuffled order: with more chunks than CUs every persistent workgroup
+    (lz_links' stream of blocks, encode's list of Huffman chunks) runs on from chunk to chunk through all of them."""
+    rs = corpus.splitmix64(977, 3000)
+    special = [0, 1, 2, 3, 4, 63, 64, 65, 2046, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 6145, 16383, 16384, 16385,
+               32505, 32506, 32507, 32768, 49152, 65534, 65535]
+    kinds = [k for k in corpus.KINDS if k != "lz"]
+    chunks = []
+    for i in range(1500):
+        n = special[i % len(special)] if i % 3 == 0 else int(rs[2 * i] % 9000) if i % 3 == 1 else int(rs[2 * i] % 65536)
+        chunks.append(corpus.make(kinds[int(rs[2 * i + 1] % len(kinds))], 7000 + i, n))
+    got = codec.deflate_chunks(chunks)
+    assert len(got) == len(chunks)
+    for i, (c, g) in enumerate(zip(chunks, got)):
+        assert g == oracle.payload(c), (i, len(c))
+    back, status = codec.inflate_chunks(got)
+    for i, (g, b) in enumerate(zip(got, back)):
+        want, _, _ = oracle.inflate(g, 65535)                             # (a payload cut at 65 535 bytes decodes short, as in the reference)
+        assert b == want, (i, len(chunks[i]), status[i])
+
+
 def test_deflate_golden_chunks(codec, golden_dir):
     rows = json.load(open(os.path.join(golden_dir, "chunks.json")))
     chunks = [corpus.make(r["kind"], r["seed"], r["n"]) for r in rows]
