@@ -1387,16 +1387,20 @@ static __device__ __forceinline__ uint32_t lane_huffman_cost(uint16_t* a, uint32
 }
 
 constexpr uint32_t kCostLaneWords = 161;   // 160 words of sorted counts per lane, odd stride against bank conflicts
+constexpr uint32_t kCostLanes = 16;        // blocks per wave: a lane's row is 644 bytes and the merge is a chain of LDS round trips per lane -- with 64
+                                           // rows a wave (41 KB) three waves a CU had nothing to hide them behind: 0.51 ms per 250 000 blocks,
+                                           // 32 rows 0.33, 16 rows (fifteen waves a CU) 0.30
 __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ probes, uint32_t n_blocks_total) {
-    __shared__ uint32_t arr[64 * kCostLaneWords];
-    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u;
+    __shared__ uint32_t arr[kCostLanes * kCostLaneWords];
+    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * kCostLanes;
     const uint32_t g = g0 + lane;
-    BlockProbe* mine = probe_of(probes, g < n_blocks_total ? g : 0u);
-    const bool live = g < n_blocks_total && mine->state == kProbeOpen;
+    const bool mine_ok = lane < kCostLanes && g < n_blocks_total;
+    BlockProbe* mine = probe_of(probes, mine_ok ? g : 0u);
+    const bool live = mine_ok && mine->state == kProbeOpen;
     uint32_t m_l = 0, m_d = 0;
     if (live) { m_l = mine->m_l; m_d = mine->m_d; }
     // stage the sorted counts of every probed block of this wave: lane-private rows, coalesced copy
-    for (uint32_t j = 0; j < 64; j++) {
+    for (uint32_t j = 0; j < kCostLanes; j++) {
         const uint32_t ml = __shfl(m_l, j), md = __shfl(m_d, j);
         if (ml == 0) continue;                           // not a block (a block counts at least its end-of-block symbol)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(probe_of(probes, g0 + j)->lit);
@@ -1407,7 +1411,7 @@ __global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ 
     __syncthreads();
     uint32_t max_l = m_l, max_d = m_d;
     for (uint32_t d = 32; d >= 1; d >>= 1) { max_l = max(max_l, (uint32_t)__shfl_xor(max_l, d)); max_d = max(max_d, (uint32_t)__shfl_xor(max_d, d)); }
-    uint16_t* row = reinterpret_cast<uint16_t*>(arr + lane * kCostLaneWords);
+    uint16_t* row = reinterpret_cast<uint16_t*>(arr + (lane < kCostLanes ? lane : 0u) * kCostLaneWords);   // (lanes without a row have m = 0: they never touch it)
     const uint32_t hl = lane_huffman_cost(row, m_l, max_l);
     const uint32_t hd = lane_huffman_cost(row + 288, m_d, max_d);
     if (live) {
@@ -2348,7 +2352,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
                        a.info, a.blocks, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(plan_probe_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes);
-    hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + 63u) / 64u), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
+    hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + kCostLanes - 1u) / kCostLanes), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
     hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     {
