@@ -24,7 +24,7 @@ constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
 constexpr uint32_t kEncQueue = 128;                               // entries of a wave's queue of symbol starts (a power of two >= 127)
-constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + (kEncodeThreads / 64) * kEncQueue * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 78448: two workgroups per CU
+constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + (kEncodeThreads / 64) * kEncQueue * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 78 528 bytes: two workgroups per CU (with __launch_bounds__(1024, 8): 64 registers)
 constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
 constexpr int kNumDeflateStages = 6;
 

@@ -678,12 +678,10 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         __syncthreads();
         if (t + 1 < ntiles) ZWZ_PREFETCH(t + 1)     // in flight during the search below
 
-        // Order of work inside the tile.  A wave finishes a trip when its longest chain does, and chain
-        // lengths run from 1 to 128 among neighbouring positions (21-29% VALU lane utilisation on
-        // text).  Positions with a similar distance to their second predecessor have similar chain
-        // lengths, so the tile is counting-sorted by an 8-bucket key of that distance and waves take 64
-        // positions of one bucket at a time (~0.58 utilisation, half the trips).  Chunks with sparse
-        // chains (lz_links' count, above) take the screening pass instead.
+        // Order of work inside the tile.  A group of 64 searches lasts as long as its longest chain, and chain lengths run
+        // from 1 to 128 among neighbouring positions (21-29 % lane utilisation on text in natural order).  Chain-heavy chunks
+        // sort the tile's positions by a prediction of the chain length and hand out groups of 64 longest first (below);
+        // chunks with sparse chains (lz_links' count, above) take the screening pass instead.
         const uint32_t npos = te - ts;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = lane_id();   // (the compiler does not see tid >> 6 as wave-uniform)
         uint32_t nlist = npos;                                     // sorted order: positions on the work list (wave-uniform after the scan)
