@@ -212,146 +212,142 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         };
         uint32_t s = 0;
         if (n_steps == kLinksBlock / 64u) {
-            // A whole block (all but the last of a short chunk), straight-line: the wave issues an instruction every ~9 cycles
-            // and that is the step's time, so steps go in PAIRS -- one ds_read2 for two steps' bucket addresses, two
-            // exchanges, one ds_write2 for two steps' links: 8 instructions for 128 positions, no loop, no address
-            // arithmetic (v119..v126 = base + 1024 j; a pair's slots are a base plus constant offsets).  Three register sets
-            // take turns, in named registers -- a ds_read2 fills a register pair whose halves the exchanges use one by one,
-            // which operand constraints cannot express.  Per pair: read the addresses of pair i+1, write the links of pair i-2,
-            // exchange pair i; four LDS operations in a fixed order, so one lgkmcnt(4) in front of the write says both "the
-            // addresses of pair i are here" and "the exchanges of pair i-2 are back", with pair i-1's still in flight (dummy
-            // reads stand in for the writes the first two pairs lack): 7 instructions a pair.
+            // A whole block (all but the last of a short chunk), straight-line, steps in PAIRS -- one ds_read2 for two steps' bucket
+            // addresses, two exchanges, one ds_write2 for two steps' links -- no loop, no address arithmetic (a pair's slots are a
+            // base register plus constant offsets), named registers (a ds_read2 fills a register pair whose halves the exchanges use
+            // one by one, which operand constraints cannot express).  Software-pipelined: per pair i, read the addresses of pair
+            // i + 2, write the links of pair i - 3, exchange pair i -- three pairs of exchanges in flight (two: 3.09 ms per 50 000 chunks; three:
+            // 2.99; four: 2.99).  LDS operations complete in order, so ONE counted wait in front of the write
+            // says both "the addresses of pair i are here" and "the exchanges of pair i - 3 are back"; the text is generated,
+            // waits included, by tools/gen_links_block.py (which simulates the queue).
             asm volatile(
-                "v_add_u32 v119, 0x400, %[base]\n\t"
-                "v_add_u32 v120, 0x800, %[base]\n\t"
-                "v_add_u32 v121, 0xc00, %[base]\n\t"
-                "v_add_u32 v122, 0x1000, %[base]\n\t"
-                "v_add_u32 v123, 0x1400, %[base]\n\t"
-                "v_add_u32 v124, 0x1800, %[base]\n\t"
-                "v_add_u32 v125, 0x1c00, %[base]\n\t"
-                "v_add_u32 v126, 0x2000, %[base]\n\t"
-                "v_mov_b32 v112, %[p0]\n\t"
-                "v_add_u32 v113, 0x40, %[p0]\n\t"
-                "v_add_u32 v114, 0x80, %[p0]\n\t"
-                "v_add_u32 v115, 0xc0, %[p0]\n\t"
-                "v_add_u32 v116, 0x100, %[p0]\n\t"
-                "v_add_u32 v117, 0x140, %[p0]\n\t"
+                "v_add_u32 v116, 0x400, %[base]\n\t"
+                "v_add_u32 v117, 0x800, %[base]\n\t"
+                "v_add_u32 v118, 0xc00, %[base]\n\t"
+                "v_add_u32 v119, 0x1000, %[base]\n\t"
+                "v_add_u32 v120, 0x1400, %[base]\n\t"
+                "v_add_u32 v121, 0x1800, %[base]\n\t"
+                "v_add_u32 v122, 0x1c00, %[base]\n\t"
+                "v_mov_b32 v114, %[p0]\n\t"
+                "v_add_u32 v115, 0x40, %[p0]\n\t"
                 "ds_read2_b32 v[100:101], %[base] offset1:64\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
                 "ds_read2_b32 v[102:103], %[base] offset0:128 offset1:192\n\t"
-                "ds_read_b32 v118, %[base]\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "v_add_u32 v112, 0x180, v112\n\t"
-                "v_add_u32 v113, 0x180, v113\n\t"
-                "ds_read2_b32 v[104:105], v119 offset1:64\n\t"
+                "ds_read2_b32 v[104:105], v116 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[100:101], v116 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_read_b32 v118, %[base]\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "v_add_u32 v114, 0x180, v114\n\t"
-                "v_add_u32 v115, 0x180, v115\n\t"
-                "ds_read2_b32 v[100:101], v119 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[102:103], v117 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v114\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[104:105], v117 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
                 "ds_write2_b32 %[base], v106, v107 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
-                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "v_add_u32 v116, 0x180, v116\n\t"
-                "v_add_u32 v117, 0x180, v117\n\t"
-                "ds_read2_b32 v[102:103], v120 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v112, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v113, v101, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[100:101], v118 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(7)\n\t"
                 "ds_write2_b32 %[base], v108, v109 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "v_add_u32 v112, 0x180, v112\n\t"
-                "v_add_u32 v113, 0x180, v113\n\t"
+                "ds_wrxchg_rtn_b32 v106, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v107, v103, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[102:103], v118 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v116, v110, v111 offset1:64\n\t"
+                "ds_wrxchg_rtn_b32 v108, v104, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v105, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[104:105], v119 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v116, v112, v113 offset0:128 offset1:192\n\t"
+                "ds_wrxchg_rtn_b32 v110, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v111, v101, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[100:101], v119 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v117, v106, v107 offset1:64\n\t"
+                "ds_wrxchg_rtn_b32 v112, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v113, v103, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[102:103], v120 offset1:64\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v117, v108, v109 offset0:128 offset1:192\n\t"
+                "ds_wrxchg_rtn_b32 v106, v104, v114\n\t"
+                "ds_wrxchg_rtn_b32 v107, v105, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
                 "ds_read2_b32 v[104:105], v120 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v119, v110, v111 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
-                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "v_add_u32 v114, 0x180, v114\n\t"
-                "v_add_u32 v115, 0x180, v115\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v118, v110, v111 offset1:64\n\t"
+                "ds_wrxchg_rtn_b32 v108, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v109, v101, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
                 "ds_read2_b32 v[100:101], v121 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v119, v106, v107 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
-                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "v_add_u32 v116, 0x180, v116\n\t"
-                "v_add_u32 v117, 0x180, v117\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v118, v112, v113 offset0:128 offset1:192\n\t"
+                "ds_wrxchg_rtn_b32 v110, v102, v114\n\t"
+                "ds_wrxchg_rtn_b32 v111, v103, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
                 "ds_read2_b32 v[102:103], v121 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v120, v108, v109 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "v_add_u32 v112, 0x180, v112\n\t"
-                "v_add_u32 v113, 0x180, v113\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v119, v106, v107 offset1:64\n\t"
+                "ds_wrxchg_rtn_b32 v112, v104, v114\n\t"
+                "ds_wrxchg_rtn_b32 v113, v105, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
                 "ds_read2_b32 v[104:105], v122 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v120, v110, v111 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v119, v108, v109 offset0:128 offset1:192\n\t"
+                "ds_wrxchg_rtn_b32 v106, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v107, v101, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "ds_read2_b32 v[100:101], v122 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "ds_write2_b32 v120, v110, v111 offset1:64\n\t"
                 "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
                 "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "v_add_u32 v114, 0x180, v114\n\t"
-                "v_add_u32 v115, 0x180, v115\n\t"
-                "ds_read2_b32 v[100:101], v122 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "s_waitcnt lgkmcnt(7)\n\t"
+                "ds_write2_b32 v120, v112, v113 offset0:128 offset1:192\n\t"
+                "ds_wrxchg_rtn_b32 v110, v104, v114\n\t"
+                "ds_wrxchg_rtn_b32 v111, v105, v115\n\t"
+                "v_add_u32 v114, 0x80, v114\n\t"
+                "v_add_u32 v115, 0x80, v115\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
                 "ds_write2_b32 v121, v106, v107 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
-                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "v_add_u32 v116, 0x180, v116\n\t"
-                "v_add_u32 v117, 0x180, v117\n\t"
-                "ds_read2_b32 v[102:103], v123 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
+                "ds_wrxchg_rtn_b32 v112, v100, v114\n\t"
+                "ds_wrxchg_rtn_b32 v113, v101, v115\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
                 "ds_write2_b32 v121, v108, v109 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "v_add_u32 v112, 0x180, v112\n\t"
-                "v_add_u32 v113, 0x180, v113\n\t"
-                "ds_read2_b32 v[104:105], v123 offset0:128 offset1:192\n\t"
                 "s_waitcnt lgkmcnt(4)\n\t"
                 "ds_write2_b32 v122, v110, v111 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
-                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "v_add_u32 v114, 0x180, v114\n\t"
-                "v_add_u32 v115, 0x180, v115\n\t"
-                "ds_read2_b32 v[100:101], v124 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v122, v106, v107 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
-                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "v_add_u32 v116, 0x180, v116\n\t"
-                "v_add_u32 v117, 0x180, v117\n\t"
-                "ds_read2_b32 v[102:103], v124 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v123, v108, v109 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "v_add_u32 v112, 0x180, v112\n\t"
-                "v_add_u32 v113, 0x180, v113\n\t"
-                "ds_read2_b32 v[104:105], v125 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v123, v110, v111 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v108, v102, v114\n\t"
-                "ds_wrxchg_rtn_b32 v109, v103, v115\n\t"
-                "ds_read2_b32 v[100:101], v125 offset0:128 offset1:192\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v124, v106, v107 offset1:64\n\t"
-                "ds_wrxchg_rtn_b32 v110, v104, v116\n\t"
-                "ds_wrxchg_rtn_b32 v111, v105, v117\n\t"
-                "ds_read2_b32 v[102:103], v126 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v124, v108, v109 offset0:128 offset1:192\n\t"
-                "ds_wrxchg_rtn_b32 v106, v100, v112\n\t"
-                "ds_wrxchg_rtn_b32 v107, v101, v113\n\t"
-                "s_waitcnt lgkmcnt(4)\n\t"
-                "ds_write2_b32 v125, v110, v111 offset1:64\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "ds_write2_b32 v125, v106, v107 offset0:128 offset1:192\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "ds_write2_b32 v122, v112, v113 offset0:128 offset1:192\n\t"
                 "s_nop 0"
+
                 :
                 : [base] "v"(base), [p0] "v"(p0)
-                : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",
-                  "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+                : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122");
             s = n_steps;
         } else if (n_steps >= 6u) {
             // steps s, s+1 issued; bucket addresses of s+2, s+3 at hand; then three steps a trip: read the address of step t+2,
