@@ -1740,6 +1740,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
 #pragma unroll 1
         for (uint32_t u0 = 0; u0 < 16u; u0 += 4u) {                       // four loads in flight (sixteen pushed this kernel's 64 registers into scratch)
+            if (u0 * kEncodeThreads * 4u >= L) break;                     // (workgroup-uniform: a short chunk has nothing there)
             uint32_t w[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) { const uint32_t i = (tid + (u0 + u) * kEncodeThreads) * 4u; w[u] = i < L ? d32[i >> 2] : 0u; }
