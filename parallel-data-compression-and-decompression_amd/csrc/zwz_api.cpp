@@ -55,26 +55,40 @@ int links_self_test(zwz_ctx* c) {
         }
     }
     uint8_t* d_in = nullptr; uint64_t* d_off = nullptr; uint32_t* d_len = nullptr; uint16_t* d_links = nullptr; uint32_t* d_stat = nullptr;
-    auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_links); (void)hipFree(d_stat); };
+    uint32_t *d_sorted = nullptr, *d_list = nullptr, *d_tickets = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_in); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_links); (void)hipFree(d_stat);
+                         (void)hipFree(d_sorted); (void)hipFree(d_list); (void)hipFree(d_tickets); };
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), h_in.size());
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_off), sizeof offs);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_len), sizeof lens);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_links), K * (size_t)kLinkStride * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), K * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_sorted), K * (size_t)kSortedStride * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_list), K * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_tickets), kTicketBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tickets, 0, kTicketBytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_sorted, 0xa5, K * (size_t)kSortedStride * sizeof(uint32_t), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, h_in.data(), h_in.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, offs, sizeof offs, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_len, lens, sizeof lens, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_links, 0xa5, K * (size_t)kLinkStride * sizeof(uint16_t), c->stream);
     DeflateArgs a{};
     a.in = d_in; a.in_off = d_off; a.in_len = d_len; a.n = K; a.links = d_links; a.link_stat = d_stat; a.cu_count = 3;
+    a.sorted = d_sorted; a.dense_list = d_list; a.tickets = d_tickets;
     if (e == hipSuccess) e = launch_links_only(a, c->stream);
     std::vector<uint16_t> got(K * (size_t)kLinkStride);
     uint32_t stat[K] = {};
     if (e == hipSuccess) e = hipMemcpyAsync(got.data(), d_links, got.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(stat, d_stat, sizeof stat, hipMemcpyDeviceToHost, c->stream);
+    // lz_sort over the same chunks (it overwrites their link arrays, read back above): its ranking pass stands on the lane
+    // order of the returning LDS add
+    std::vector<uint32_t> srt(K * (size_t)kSortedStride);
+    if (e == hipSuccess) e = launch_dense_list(a, c->stream, 2u);
+    if (e == hipSuccess) e = launch_sort(a, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(srt.data(), d_sorted, srt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
-    if (e != hipSuccess) return hip_fail(e, "lz_links self-test");
+    if (e != hipSuccess) return hip_fail(e, "lz_links / lz_sort self-test");
     std::vector<uint16_t> head(32768);
     for (uint32_t k = 0; k < K; k++) {
         const uint8_t* d = h_in.data() + (size_t)k * ZWZ_DEV_STRIDE;
@@ -95,6 +109,19 @@ int links_self_test(zwz_ctx* c) {
             if (got[(size_t)k * kLinkStride + p] != 0) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: a link behind the last trigram)", k); return ZWZ_E_NO_DEVICE; }
         }
         if (stat[k] != linked) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: %u linked positions counted, %u expected)", k, stat[k], linked); return ZWZ_E_NO_DEVICE; }
+        // the sorted array: a stable counting sort of the positions by bucket
+        const uint32_t n = lens[k] >= kMinMatch ? lens[k] - (kMinMatch - 1u) : 0u;
+        std::vector<uint32_t> start(32769, 0);
+        for (uint32_t p = 0; p < n; p++) start[hash3(d[p], d[p + 1], d[p + 2]) + 1]++;
+        for (uint32_t h = 0; h < 32768; h++) start[h + 1] += start[h];
+        for (uint32_t p = 0; p < n; p++) {
+            const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]), want = h << 16 | p, at = start[h]++;
+            if (srt[(size_t)k * kSortedStride + at] != want) {
+                set_error("zwz_ctx_create: lz_sort self-test failed (chunk %u, sorted index %u: %08x, expected %08x) -- the returning LDS add does not "
+                          "serve same-address lanes in lane order on this device", k, at, srt[(size_t)k * kSortedStride + at], want);
+                return ZWZ_E_NO_DEVICE;
+            }
+        }
     }
     return ZWZ_OK;
 }
@@ -338,6 +365,8 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.perm = reinterpret_cast<uint16_t*>(take(n * kTile * sizeof(uint16_t)));
     a.link_stat = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
     a.tickets = reinterpret_cast<uint32_t*>(take(kTicketBytes));
+    a.sorted = reinterpret_cast<uint32_t*>(take(n * kSortedStride * sizeof(uint32_t)));
+    a.dense_list = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
     a.cu_count = c->cu_count;
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));

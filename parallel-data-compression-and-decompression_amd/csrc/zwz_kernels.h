@@ -19,6 +19,11 @@ constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-3
 constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
 constexpr uint32_t kMatchListBytes = 4096 + 10240;               // bucket counts of a sorted tile / per-wave work lists of a sparse tile
 constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163520 of 163840 (with 64 static)
+constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) words of lz_sort, sorted by (bucket, position)
+constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
+constexpr uint32_t kBandThreads = 1024;
+constexpr uint32_t kBandTile = 5632;                             // sorted entries per tile of lz_match_band (88 groups of 64)
+constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 154 176
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
@@ -70,7 +75,9 @@ struct DeflateArgs {
     uint16_t* links; uint2* entries; uint64_t* has128; uint64_t* sym; uint64_t* mst;
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
-    uint32_t* tickets;         // kTicketBytes of counters (encode's list of Huffman chunks and its hand-out; zeroed by launch_deflate)
+    uint32_t* tickets;         // kTicketBytes of counters (kTicket*; zeroed by launch_deflate)
+    uint32_t* sorted;          // lz_sort -> lz_match_band: kSortedStride words per chunk
+    uint32_t* dense_list;      // chunks that take the sort + band path (lz_dense_list), tickets[kTicketDenseCount] of them
     uint32_t cu_count;         // sizes the persistent grids (0: 256)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
@@ -84,14 +91,21 @@ struct InflateArgs {
 };
 
 constexpr size_t kTicketBytes = 256;
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4 };   // indices into DeflateArgs::tickets
+// Chain-heavy chunk (four positions in five have a chain predecessor, lz_links' count): sort + band; else lz_match's screening pass.
+__host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
 constexpr size_t kWorkspaceBytesPerChunk =
-    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) +
+    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) + (size_t)kSortedStride * 4 + 4 +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
 
 hipError_t configure_kernels();
 hipError_t probe_exchange_order(hipStream_t s, bool* holds);   // see exchange_order_probe_kernel
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* stage_events);
 hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s);
+hipError_t configure_band_kernels();
+hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which);   // 0: by lz_links' count, 1: no chunk, 2: every chunk
+hipError_t launch_sort(const DeflateArgs& a, hipStream_t s);
+hipError_t launch_match_band(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,
                             uint32_t* digests, hipStream_t s);

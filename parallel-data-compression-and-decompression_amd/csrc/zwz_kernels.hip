@@ -21,6 +21,8 @@
 // All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "huff_core.h"
@@ -28,15 +30,9 @@
 #include "lz_core.h"
 #include "zwz_md5.h"
 #include "zwz_kernels.h"
+#include "zwz_device.h"
 
 namespace zwz {
-
-static __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-static __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
-// set bits of a wave mask below this lane (v_mbcnt pair: two instructions against four for popc(m & lanes_below()))
-static __device__ __forceinline__ uint32_t rank_in(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 
 // a chunk's dead link space: its kMaxBlocks BlockProbes first, its chosen records from kChosenOffset on
 static __device__ __forceinline__ BlockProbe* probe_of(BlockProbe* probes_base, uint32_t g) {
@@ -48,18 +44,6 @@ static __device__ __forceinline__ const BlockProbe* probe_of(const BlockProbe* p
 }
 static __device__ __forceinline__ uint32_t* chosen_of(const uint16_t* links, uint32_t chunk) {
     return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(links + (size_t)chunk * kLinkStride)) + kChosenOffset);
-}
-
-// Inclusive add-scan over the wave with DPP row shifts and broadcasts: six VALU instructions.  (`__shfl_up` is a
-// ds_bpermute -- an LDS-pipeline operation -- and the encoder scans once per 64 symbols with 32 waves on the CU.)
-static __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,20 +462,6 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 #undef ZWZ_LINKS_HANDOVER
 }
 
-// Workgroup copy of n 16-byte vectors global -> LDS with eight loads in flight per thread.
-static __device__ __forceinline__ void copy_vec16(uint4* dst, const uint4* src, uint32_t n) {
-    const uint32_t T = blockDim.x;
-    uint32_t i = threadIdx.x;
-    for (; i + 7 * T < n; i += 8 * T) {
-        uint4 r[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) r[u] = src[i + u * T];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) dst[i + u * T] = r[u];
-    }
-    for (; i < n; i += T) dst[i] = src[i];
-}
-
 // lz_core.h's lz_search, restated for a whole wave: same candidates, same order, same records.
 // The chain walk is the framework's hottest loop.  Written per lane it compiles to ~32 instructions
 // per candidate, a third of them exec-mask bookkeeping for the per-lane exits; a predicated C++
@@ -619,11 +589,12 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128,
-                                                                 uint16_t* __restrict__ perms, const uint32_t* __restrict__ link_stat) {
+                                                                 uint16_t* __restrict__ perms, const uint32_t* __restrict__ link_stat,
+                                                                 uint32_t band /* 0: every chunk is this kernel's, 1: chain-heavy chunks are lz_match_band's, 2: all are */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
-    if (L == 0) return;
+    if (L == 0 || band == 2u || (band == 1u && chunk_is_dense(link_stat[chunk], L))) return;
     uint8_t* sdata = smem;
     uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
     uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // 2 KiB: has128 bits of a tile
@@ -658,7 +629,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     }
     // chain-heavy data (four of five positions have a chain predecessor: text) takes the sorted work order, sparse
     // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
-    const bool sorted_order = link_stat[chunk] * 5u >= L * 4u;      // workgroup-uniform
+    const bool sorted_order = chunk_is_dense(link_stat[chunk], L);  // workgroup-uniform
     for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
     uint32_t org = 0;
     ZWZ_PREFETCH(0u)
@@ -1601,7 +1572,6 @@ static __device__ __forceinline__ void encode_stored_chunk(const uint8_t* __rest
 // 81 KB workgroups a CU, a stored chunk cost ~12 us whatever its length: 1.7 ms per 50 000).  Every other chunk goes onto the
 // list encode_kernel works through.
 constexpr uint32_t kEncStoredThreads = 256;
-constexpr uint32_t kTicketHuffCount = 0, kTicketHuffNext = 1;      // indices into DeflateArgs::tickets
 
 __global__ __launch_bounds__(kEncStoredThreads) void encode_stored_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                           const uint32_t* __restrict__ in_len, const ChunkInfo* __restrict__ info,
@@ -1875,16 +1845,6 @@ constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per w
 constexpr uint32_t kWinParts = 2;          // windows a round may look at
 
 constexpr uint32_t kOwnCap = 1024;         // batch bytes the per-byte owner map covers (a batch is <= 64 symbols: ~300 bytes on text)
-
-static __device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v) {          // as wave_scan_incl, with max (0 = identity)
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
-    return v;
-}
 
 struct InflateWaveMem {
     InflateTables t;
@@ -2334,7 +2294,7 @@ hipError_t configure_kernels() {
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(exchange_order_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
-    return hipSuccess;
+    return configure_band_kernels();
 }
 
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /* kNumDeflateStages + 1 or null */) {
@@ -2343,8 +2303,16 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
     ZWZ_TRY(launch_links(a, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
+    // chain-heavy chunks: positions sorted by (bucket, position), then the banded search (zwz_band.hip); the rest: lz_match's
+    // screening pass over the links.  ZWZ_MATCH=walk sends every chunk through lz_match, =band every chunk through the band.
+    const uint32_t which = [] { const char* e = getenv("ZWZ_MATCH"); return e && !strcmp(e, "walk") ? 1u : e && !strcmp(e, "band") ? 2u : 0u; }();   // (read per launch: tests flip it)
+    ZWZ_TRY(launch_dense_list(a, s, which));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
-                       a.links, a.entries, a.has128, a.perm, a.link_stat);
+                       a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u);
+    if (which != 1u) {
+        ZWZ_TRY(launch_sort(a, s));
+        ZWZ_TRY(launch_match_band(a, s));
+    }
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));

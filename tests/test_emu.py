@@ -52,3 +52,58 @@ def test_cores_match_libz_fuzz(emu):
             n //= 3
         data = corpus.make(kind, 7000 + i, n)
         assert emu_binding.chunk_stream(emu, data) == zlib.compress(data, 6), (kind, n)
+
+
+def _records(emu, data):
+    import ctypes
+    n = len(data)
+    a = (ctypes.c_uint32 * (n + 1))(); b = (ctypes.c_uint32 * (n + 1))()
+    out = ctypes.create_string_buffer(70000)
+    emu.emu_chunk_stream(data, n, out, 70000, a, b)
+    return list(a)[:n], list(b)[:n]
+
+
+def _band(emu, data, tile, fmt):
+    import ctypes
+    n = len(data)
+    a = (ctypes.c_uint32 * (n + 1))(); b = (ctypes.c_uint32 * (n + 1))()
+    pure = emu.emu_band_records(data, n, tile, fmt, a, b)
+    return list(a)[:n], list(b)[:n], pure
+
+
+@pytest.mark.parametrize("kind", list(corpus.KINDS))
+def test_banded_search_gives_lz_search_records(emu, kind):
+    """csrc/lz_band.h (sorted positions, banded keys, sharer chains) against csrc/lz_core.h's chain walk, record by record:
+    both 8-byte formats, tiles small enough that chains cross halos."""
+    for i, n in enumerate([0, 1, 2, 3, 4, 11, 12, 13, 300, 4097, 20000, 40000, 65274 + 7, 65535]):
+        if kind == "lz" and 20000 < n < 65535:
+            continue
+        data = corpus.make(kind, 5000 + i, n)
+        want = _records(emu, data)
+        for tile, fmt in ((5632, -1), (5632, 0), (192, -1), (64, 0)):
+            if tile < 1000 and n > 20000:
+                continue
+            got = _band(emu, data, tile, fmt)
+            assert got[0] == want[0], (kind, n, tile, fmt, "e128")
+            assert got[1] == want[1], (kind, n, tile, fmt, "e32")
+
+
+def test_banded_search_corners(emu):
+    # a first candidate at exactly MAX_DIST (allowed), at MAX_DIST once zlib's window has slid (not allowed), position 0 as the
+    # only earlier occurrence (NIL), long runs that stop at `nice`, the chunk's last positions
+    base = bytearray(corpus.random_bytes(4242, 65535))
+    cases = []
+    a = bytearray(base); a[32506 + 100:32506 + 120] = a[100:120]; cases.append(bytes(a))
+    a = bytearray(base); a[65274:65274 + 12] = a[32768:32768 + 12]; cases.append(bytes(a))
+    a = bytearray(base); a[65275:65275 + 12] = a[32769:32769 + 12]; cases.append(bytes(a))
+    a = bytearray(base); a[5000:5040] = a[0:40]; cases.append(bytes(a))
+    a = bytearray(base); a[65535 - 40:] = a[1000:1040]; cases.append(bytes(a))
+    a = bytearray(base); a[65535 - 9:] = a[1000:1009]; a[65535 - 300:65535 - 291] = a[1000:1009]; cases.append(bytes(a))
+    cases.append(bytes(b"abcabcabd" * 7000)[:65535])
+    cases.append(corpus.text_like(77, 65535, vocab=64))
+    cases.append(bytes(corpus.text_like(78, 30000)) + corpus.random_bytes(79, 20000) + bytes(15535))
+    for idx, data in enumerate(cases):
+        want = _records(emu, data)
+        for tile, fmt in ((5632, -1), (5632, 0), (1024, -1)):
+            got = _band(emu, data, tile, fmt)
+            assert got[0] == want[0] and got[1] == want[1], (idx, tile, fmt)

@@ -42,6 +42,21 @@ def test_deflate_matches_oracle(codec, oracle, kind):
         assert g == oracle.payload(c), (kind, len(c))
 
 
+@pytest.mark.parametrize("flavour", ["band", "walk"])
+def test_deflate_match_flavours_agree_with_oracle(codec, oracle, flavour, monkeypatch):
+    """Production picks a chunk's match kernel by its chain density (lz_sort + lz_match_band for chain-heavy chunks,
+    lz_match's screening pass for the rest).  ZWZ_MATCH (read per launch) sends EVERY chunk through one of them: each must
+    give the oracle's payloads on every kind of content -- sparse chunks through the band (mixed-trigram buckets: the
+    8-byte words start at the trigram), chain-heavy ones through the walk."""
+    monkeypatch.setenv("ZWZ_MATCH", flavour)
+    sizes = [0, 1, 2, 3, 4, 11, 12, 13, 64, 65, 300, 4097, 5632, 5634, 5635, 11266, 20000, 32506, 32507, 40000, 65274, 65284, 65535]
+    for kind in corpus.KINDS:
+        chunks = [corpus.make(kind, 8100 + i, n) for i, n in enumerate(sizes) if not (kind == "lz" and 20000 < n < 65535)]
+        got = codec.deflate_chunks(chunks)
+        for c, g in zip(chunks, got):
+            assert g == oracle.payload(c), (flavour, kind, len(c))
+
+
 def test_deflate_ragged_batch_crosses_chunk_boundaries(codec, oracle):
     """One batch of 1500 chunks of every kind of length -- empty, shorter than a trigram, around lz_links' 2048-position
     block, around the 16 Ki tile, full -- in a shuffled order: with more chunks than CUs every persistent workgroup
