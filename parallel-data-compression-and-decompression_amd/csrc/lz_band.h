@@ -12,7 +12,9 @@
 //   * a position whose best candidate agrees on all eight bytes is finished by a second pass that visits only the
 //     candidates agreeing on all eight (its "sharers", chained nearest-first through link[]), comparing real bytes;
 //   * zlib's short chain (32 candidates once the previous match is "good") is the key after the 32nd candidate.
-// The last positions of a chunk (lookahead < kBandTailLook) take band_generic(): their eight bytes reach past the data.
+// The last positions of a chunk (lookahead < kDeep): their eight bytes reach past the data, so their XORs are masked
+// down to the bytes that exist (band_tail_mask) -- "all of them agree" then means "agrees to the end of the data", which
+// is as long as a match can get there (and zlib stops at the first such candidate: the nearest).
 //
 // Portable (host + device): tests/emu builds band_records() on the CPU and diffs it against lz_search().
 #pragma once
@@ -21,7 +23,6 @@
 namespace zwz {
 
 constexpr uint32_t kBand = kMaxChain;            // candidates a position may look at: the band's width
-constexpr uint32_t kBandTailLook = 11;           // positions with less lookahead than this take the generic path
 constexpr uint32_t kBandNoLink = 0xffffu;
 constexpr uint32_t kBandHaloWord = 0xffff0000u;  // "no entry": bucket 0xffff (no hash is), position 0
 
@@ -77,14 +78,28 @@ ZWZ_HD uint32_t band_key(uint32_t own_lo, uint32_t own_hi, uint32_t c_lo, uint32
     const uint32_t t = band_ctz64(own_lo ^ c_lo, own_hi ^ c_hi);
     return ((t & 0x78u) << 5) | (129u - k);
 }
+// Masked form for a position whose word reaches past the end of the data: only the first `nbytes` bytes count.
+ZWZ_HD uint32_t band_key_masked(uint32_t own_lo, uint32_t own_hi, uint32_t c_lo, uint32_t c_hi, uint32_t m_lo, uint32_t m_hi, uint32_t k) {
+    const uint32_t t = band_ctz64((own_lo ^ c_lo) & m_lo, (own_hi ^ c_hi) & m_hi);
+    return ((t & 0x78u) << 5) | (129u - k);
+}
+ZWZ_HD uint32_t band_tail_bytes(bool pure, uint32_t lookahead) {       // bytes of the word inside the data (lookahead >= 3)
+    const uint32_t nb = pure ? lookahead - 3u : lookahead;
+    return nb < 8u ? nb : 8u;
+}
+ZWZ_HD uint32_t band_tail_mask(uint32_t nbytes, uint32_t word /* 0 = low, 1 = high */) {
+    const uint32_t nb = nbytes > 4u * word ? nbytes - 4u * word : 0u;
+    return nb >= 4u ? 0xffffffffu : (1u << (8u * nb)) - 1u;
+}
 constexpr uint32_t kBandKeyNonePure = 0u;          // below every key
 constexpr uint32_t kBandKeyNoneImpure = 0x2ffu;    // above every key of fewer than three equal bytes: the trigram itself differs
 ZWZ_HD uint32_t band_key_len(uint32_t key) { return key >> 8; }            // equal bytes of the eight, 15 = all
 ZWZ_HD uint32_t band_key_k(uint32_t key) { return 129u - (key & 0xffu); }
 
-// Record of a key that is not "all eight agree": cand = sorted-array word of the winner.
-ZWZ_HD uint32_t band_record(uint32_t key, bool pure, uint32_t p, uint32_t cand_pos) {
-    const uint32_t len = band_key_len(key) + (pure ? 3u : 0u), dist = p - cand_pos;
+// Record of a key: cand = position of the winner.  "All eight agree" (15) is a record only for a tail position, whose
+// match then runs to the end of the data (lookahead bytes); elsewhere it is the second pass's business.
+ZWZ_HD uint32_t band_record(uint32_t key, bool pure, uint32_t p, uint32_t cand_pos, uint32_t tail_len = 0) {
+    const uint32_t len = band_key_len(key) == 15u ? tail_len : band_key_len(key) + (pure ? 3u : 0u), dist = p - cand_pos;
     if (len == kMinMatch && dist > kTooFar) return 0u;
     return entry_pack(len, dist);
 }
@@ -111,13 +126,13 @@ ZWZ_HD void band_generic(const uint8_t* data, SFn S, uint32_t u, uint32_t cnt, u
 // Second pass of a position whose nearest sharer is its k1-th candidate: the sharers, nearest first, compared byte by
 // byte from kDeep on.  link(j) -> array index of the nearest sharer of entry j, kBandNoLink if none in ITS band; valid
 // for the tile's own entries (j >= first_own) -- through the halo in front of them the sharers are found by their
-// eight bytes (E(j) -> the 8-byte word as lo | hi << 32).
+// eight bytes (E(j) -> the 8-byte word as lo | hi << 32, asked for halo entries only).
 template <class SFn, class LinkFn, class EFn>
 ZWZ_HD void band_deep(const uint8_t* data, SFn S, LinkFn link, EFn E, uint32_t first_own, uint32_t u, uint32_t cnt, uint32_t k1,
-                      uint32_t deep, uint32_t L, uint32_t& e128, uint32_t& e32 /* in: the first pass's, kept if k1 > 32 */) {
+                      uint32_t deep, uint32_t L, uint64_t own /* entry u's 8-byte word */, uint32_t& e128,
+                      uint32_t& e32 /* in: the first pass's, kept if k1 > 32 */) {
     const uint32_t p = band_pos(S(u)), lookahead = L - p;
     const uint32_t max_len = lookahead < kMaxMatch ? lookahead : kMaxMatch, nice = lookahead < kNiceLen ? lookahead : kNiceLen;
-    const uint64_t own = E(u);
     uint32_t best = 0, best_pos = 0, snap = 0xffffffffu;
     uint32_t j = u - k1;
     for (;;) {

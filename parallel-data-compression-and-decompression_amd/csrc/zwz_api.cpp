@@ -115,10 +115,11 @@ int links_self_test(zwz_ctx* c) {
         for (uint32_t p = 0; p < n; p++) start[hash3(d[p], d[p + 1], d[p + 2]) + 1]++;
         for (uint32_t h = 0; h < 32768; h++) start[h + 1] += start[h];
         for (uint32_t p = 0; p < n; p++) {
-            const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]), want = h << 16 | p, at = start[h]++;
-            if (srt[(size_t)k * kSortedStride + at] != want) {
-                set_error("zwz_ctx_create: lz_sort self-test failed (chunk %u, sorted index %u: %08x, expected %08x) -- the returning LDS add does not "
-                          "serve same-address lanes in lane order on this device", k, at, srt[(size_t)k * kSortedStride + at], want);
+            const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]), want = start[h]++;
+            const uint32_t got_d = reinterpret_cast<const uint16_t*>(srt.data() + (size_t)k * kSortedStride)[p];
+            if (got_d != want) {
+                set_error("zwz_ctx_create: lz_sort self-test failed (chunk %u, position %u: sorted index %u, expected %u) -- the returning LDS add does not "
+                          "serve same-address lanes in lane order on this device", k, p, got_d, want);
                 return ZWZ_E_NO_DEVICE;
             }
         }

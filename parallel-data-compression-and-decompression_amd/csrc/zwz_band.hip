@@ -17,6 +17,18 @@
 #include "zwz_kernels.h"
 #include "zwz_device.h"
 
+#ifndef ZWZ_BAND_EXP
+#define ZWZ_BAND_EXP 0     // timing experiments only (tools/band_exp.sh): 1 = no second pass, 2 = no band loop, 4 = no candidate counts
+#endif
+
+// (ZWZ_BAND_EXP & 16: thread 0 of every workgroup adds the cycles it spent per phase, >> 8, to tickets[16 + phase]; launch_deflate
+// prints them when ZWZ_BAND_TIMES is set)
+#if ZWZ_BAND_EXP & 16
+#define ZWZ_STAMP(ph) do { if (tid == 0) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&tickets[16 + (ph)], (uint32_t)((now_ - stamp_) >> 8)); stamp_ = now_; } } while (0)
+#else
+#define ZWZ_STAMP(ph) do { } while (0)
+#endif
+
 namespace zwz {
 
 // ------------------------------------------------------------------------------------------------
@@ -59,23 +71,43 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         const uint32_t* d32 = reinterpret_cast<const uint32_t*>(in + in_off[chunk]);   // 16-byte aligned; readable to L rounded up to 16
         const uint32_t nd = ((L + 15u) & ~15u) >> 2;
         uint16_t* hb = hbuf + (size_t)chunk * kLinkStride;
-        uint32_t* out = sorted + (size_t)chunk * kSortedStride;
+        uint16_t* out = reinterpret_cast<uint16_t*>(sorted + (size_t)chunk * kSortedStride);   // dest[p]: p's index in (bucket, position) order
         {
             uint4* t4 = reinterpret_cast<uint4*>(tab);
             for (uint32_t i = tid; i < 4096u; i += kSortThreads) t4[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        // histogram: a thread takes four positions a trip (one dword and its successor); the hashes go out to hbuf for the ranking
-        for (uint32_t i = tid; 4u * i < n; i += kSortThreads) {
-            const uint32_t w0 = d32[i], w1 = i + 1u < nd ? d32[i + 1u] : 0u;
-            uint32_t h[4];
+        // histogram: a thread takes sixteen positions a trip (a 16-byte vector and the dword behind it), eight trips' loads in flight
+        // together (one at a time this loop was sixty-four HBM round trips: most of the kernel); the hashes go out to hbuf for the ranking
+        {
+            const uint4* d4 = reinterpret_cast<const uint4*>(d32);
+            const uint32_t nv = nd >> 2;                                        // 16-byte vectors of the slot
+#pragma unroll 1
+            for (uint32_t i0 = tid; 16u * i0 < n; i0 += 8u * kSortThreads) {
+                uint4 v[8]; uint32_t nx[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t x = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;
-                h[j] = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
-                if (4u * i + j < n) atomicAdd(&tab[h[j] >> 1], (h[j] & 1u) ? 0x10000u : 1u);
+                for (uint32_t r = 0; r < 8; r++) {
+                    const uint32_t i = i0 + r * kSortThreads;
+                    v[r] = i < nv ? d4[i] : make_uint4(0, 0, 0, 0);
+                    nx[r] = i + 1u < nv ? d32[4u * i + 4u] : 0u;
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < 8; r++) {
+                    const uint32_t i = i0 + r * kSortThreads;
+                    if (16u * i >= n) break;
+                    const uint32_t w[5] = {v[r].x, v[r].y, v[r].z, v[r].w, nx[r]};
+                    uint32_t h[16];
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; j++) {
+                        const uint32_t x = (j & 3u) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1u], w[j >> 2], j & 3u) : w[j >> 2];
+                        h[j] = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
+                        if (16u * i + j < n) atomicAdd(&tab[h[j] >> 1], (h[j] & 1u) ? 0x10000u : 1u);
+                    }
+                    uint4* hb4 = reinterpret_cast<uint4*>(hb + 16u * i);
+                    hb4[0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+                    hb4[1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, h[12] | h[13] << 16, h[14] | h[15] << 16);
+                }
             }
-            *reinterpret_cast<uint2*>(hb + 4u * i) = make_uint2(h[0] | h[1] << 16, h[2] | h[3] << 16);
         }
         __syncthreads();
         // exclusive scan of the 32768 counters, in place: a wave owns 4096 dwords, 64 rows of 64
@@ -98,35 +130,89 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         }
         __syncthreads();
         // ranking: positions in order, 64 a step, by ONE wave: the returning add hands same-bucket lanes their slots in lane order
-        // (= position order), steps follow one another in program order.  Eight steps' hashes are asked for ahead.
+        // (= position order), steps follow one another in program order.
         if (wave == 0) {
             const uint32_t steps = (n + 63u) >> 6;
-            for (uint32_t s0 = 0; s0 < steps; s0 += 8u) {
-                uint32_t hv[8];
+            uint32_t hv[8];
+            auto ask = [&](uint32_t s0, uint32_t* h8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) { const uint32_t p = (s0 + j) * 64u + lane; hv[j] = p < n ? (uint32_t)hb[p] : 0xffffffffu; }
+                for (uint32_t j = 0; j < 8; j++) { const uint32_t p = (s0 + j) * 64u + lane; h8[j] = p < n ? (uint32_t)hb[p] : 0xffffffffu; }
+            };
+            ask(0u, hv);
+            for (uint32_t s0 = 0; s0 < steps; s0 += 8u) {
+                uint32_t hn[8], old[8];
+                ask(s0 + 8u, hn);                                               // the next trip's hashes are on their way while this trip ranks
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) old[j] = hv[j] != 0xffffffffu ? atomicAdd(&tab[hv[j] >> 1], (hv[j] & 1u) ? 0x10000u : 1u) : 0u;
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t p = (s0 + j) * 64u + lane, h = hv[j];
-                    if (h != 0xffffffffu) {
-                        const uint32_t old = atomicAdd(&tab[h >> 1], (h & 1u) ? 0x10000u : 1u);
-                        const uint32_t dest = (h & 1u) ? old >> 16 : old & 0xffffu;
-                        out[dest] = band_word(h, p);
-                    }
+                    const uint32_t p = (s0 + j) * 64u + lane;
+                    if (hv[j] != 0xffffffffu) out[p] = (uint16_t)((hv[j] & 1u) ? old[j] >> 16 : old[j]);
                 }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) hv[j] = hn[j];
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz_match_band.
+// lz_place: dest[p] -> the sorted array itself, position of sorted index u at spos[u].  The inverse of a permutation is a
+// scatter; done through HBM it costs a 64-line store per wave (lz_sort spent 5x its time on it), so the whole chunk's
+// array is scattered in LDS (128 KiB of 16-bit positions) and leaves as whole lines.
+__global__ __launch_bounds__(kPlaceThreads) void lz_place_kernel(const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ list,
+                                                                 uint32_t* __restrict__ tickets, uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* stage = reinterpret_cast<uint16_t*>(smem);
+    __shared__ uint32_t s_chunk;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_list = tickets[kTicketDenseCount];
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_chunk = atomicAdd(&tickets[kTicketPlaceNext], 1u);
+        __syncthreads();
+        const uint32_t t = s_chunk;
+        if (t >= n_list) break;
+        const uint32_t chunk = list[t];
+        const uint32_t L = in_len[chunk];
+        const uint32_t n = L >= kMinMatch ? L - (kMinMatch - 1u) : 0u;
+        const uint4* d4 = reinterpret_cast<const uint4*>(sorted + (size_t)chunk * kSortedStride);            // dest[p], 16 bits each
+        uint4* o4 = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(sorted + (size_t)chunk * kSortedStride) + 65536);   // spos[u]
+        uint4 d[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) if (8u * (tid + kPlaceThreads * r) < n) d[r] = d4[tid + kPlaceThreads * r];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            const uint32_t p0 = 8u * (tid + kPlaceThreads * r);
+            const uint32_t dw[4] = {d[r].x, d[r].y, d[r].z, d[r].w};
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) if (p0 + j < n) stage[(dw[j >> 1] >> (16u * (j & 1u))) & 0xffffu] = (uint16_t)(p0 + j);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; 8u * i < n; i += kPlaceThreads) o4[i] = reinterpret_cast<const uint4*>(stage)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lz_match_band.  Per chunk: bytes -> LDS, dest[] -> registers (64 positions a thread, kept for all tiles).  Per tile of
+// kBandTile sorted entries (+ the 128 in front of them):
+//   scatter   every thread looks at its 64 dests; the ones inside the tile drop (bucket << 16 | position) into their slot
+//   build     the 8-byte comparison word of every entry; "pure" (one trigram per bucket, so the word starts behind the trigram)
+//             unless two neighbours of one bucket differ in their trigrams -- then the words are rebuilt from the trigram on
+//   count     candidates per entry (binary search over the monotone band_valid, six entries a thread in flight together);
+//             the chunk's last positions are finished here, byte by byte
+//   order     runs of eight consecutive entries, sorted by their greatest count: a wave's 64 lanes are eight runs of similar
+//             length (a trip lasts as long as its longest band: 0.66 of the lanes busy in array order, 0.89 this way), and
+//             each run still reads 64 consecutive LDS bytes per step
+//   pass 1    the banded keys (see the loop)
+//   pass 2    the flagged entries, compacted into full waves, walk their sharers (csrc/lz_band.h band_deep)
 constexpr uint32_t kBandArr = kBandTile + kBand;                    // a tile's arrays: 128 halo entries, then the tile's own
 constexpr uint32_t kBandDataBytes = 65536 + 64;                     // the chunk + slack for comparisons that run past its end
 constexpr uint32_t kBandOffS = kBandDataBytes, kBandOffE = kBandOffS + kBandArr * 4, kBandOffCk = kBandOffE + kBandArr * 8,
                    kBandOffHas = kBandOffCk + kBandTile * 2;
 static_assert(kBandOffHas + 8192 == kBandLdsBytes, "lz_match_band LDS layout");
-static_assert(kBandTile % 64 == 0 && kBandOffE % 8 == 0 && kBandOffS % 16 == 0, "lz_match_band LDS alignment");
+static_assert(kBandTile % 64 == 0 && kBandOffE % 8 == 0 && kBandOffS % 16 == 0 && kBandOffCk % 16 == 0, "lz_match_band LDS alignment");
+constexpr uint32_t kBandRuns = kBandTile / 8;
 
 __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                     const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ list,
@@ -138,12 +224,20 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
     uint2* E = reinterpret_cast<uint2*>(smem + kBandOffE);
     uint16_t* ck = reinterpret_cast<uint16_t*>(smem + kBandOffCk);       // per own entry: candidates | k of the nearest sharer << 8
     uint32_t* hasb = reinterpret_cast<uint32_t*>(smem + kBandOffHas);    // has128 bits of the whole chunk
-    __shared__ uint32_t s_chunk, s_grp[2];
-    const uint32_t tid = threadIdx.x, lane = lane_id();
+    uint16_t* flist = reinterpret_cast<uint16_t*>(E + kBand);            // pass 2's work list: over the own entries' words, dead by then
+    __shared__ uint32_t s_chunk, s_grp[2], s_nflag, s_nrun;
+    __shared__ uint16_t s_halo_link[kBand];                              // the links of a tile's last 128 entries, for the next tile's halo
+    __shared__ uint32_t s_bin[132];
+    __shared__ uint16_t s_order[kBandRuns];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_list = tickets[kTicketDenseCount];
     for (uint32_t i = tid; i < 2048u; i += kBandThreads) hasb[i] = 0;
+#if ZWZ_BAND_EXP & 16
+    uint64_t stamp_ = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         __syncthreads();
+        ZWZ_STAMP(7);
         if (tid == 0) s_chunk = atomicAdd(&tickets[kTicketBandNext], 1u);
         __syncthreads();
         const uint32_t tk = s_chunk;
@@ -151,32 +245,115 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
         const uint32_t chunk = list[tk];
         const uint32_t L = in_len[chunk];
         const uint32_t n = L >= kMinMatch ? L - (kMinMatch - 1u) : 0u;
-        const uint32_t* srt = sorted + (size_t)chunk * kSortedStride;
         uint2* ent = entries + (size_t)chunk * kEntryStride;
         uint64_t* hm = has128 + (size_t)chunk * kMaskWords;
+        const uint4* spos4 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(sorted + (size_t)chunk * kSortedStride) + 65536);   // lz_place: position of sorted index u
         copy_vec16(reinterpret_cast<uint4*>(sdata), reinterpret_cast<const uint4*>(in + in_off[chunk]), (L + 15u) >> 4);
+        ZWZ_STAMP(0);
+        bool prev_pure = false;
+        // a tile's positions (eight a thread) are asked for one tile ahead: an HBM round trip per tile otherwise stands in the open
+        auto spos_of = [&](uint32_t a_) { return 8u * tid < kBandArr && 8u * tid + a_ >= kBand && 8u * tid + a_ - kBand < n ? spos4[(8u * tid + a_ - kBand) >> 3] : make_uint4(0, 0, 0, 0); };
+        static_assert(kBandArr <= 8u * kBandThreads, "a thread holds eight of a tile's positions");
+        uint4 v_next = spos_of(0u);
         for (uint32_t a = 0; a < n; a += kBandTile) {
             const uint32_t b = min(a + kBandTile, n), m = b - a + kBand;      // array index i <-> sorted index a - 128 + i
-            for (uint32_t i = tid; i < m; i += kBandThreads) S[i] = a + i >= kBand ? srt[a + i - kBand] : kBandHaloWord;
-            if (tid == 0) { s_grp[0] = 0; s_grp[1] = 0; }
+            if (a < kBand) for (uint32_t i = tid; i < kBand - a; i += kBandThreads) S[i] = kBandHaloWord;   // (a = 0: the first tile)
+            if (tid == 0) { s_grp[0] = 0; s_grp[1] = 0; s_nflag = 0; s_nrun = 0; }
+            if (tid < 132u) s_bin[tid] = 0;
             __syncthreads();                                                  // (also: the chunk's bytes are in place)
-            // one trigram per bucket within the tile's reach?  (each entry against the one in front of it)
-            bool mixed = false;
-            for (uint32_t i = tid; i < m; i += kBandThreads) {
-                const uint32_t w = S[i], wp = i ? S[i - 1u] : kBandHaloWord;
-                if (w != kBandHaloWord && wp != kBandHaloWord && band_hash(w) == band_hash(wp))
-                    mixed |= ((load_u32(sdata, band_pos(w)) ^ load_u32(sdata, band_pos(wp))) & 0xffffffu) != 0u;
+            // ---- the tile's entries and the 128 in front of them: positions from lz_place's array, buckets from the bytes
+            {
+                const uint32_t pw[4] = {v_next.x, v_next.y, v_next.z, v_next.w};
+                if (8u * tid + a >= kBand) {                                    // (before the array's start: halo words, set above)
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t p = (pw[j >> 1] >> (16u * (j & 1u))) & 0xffffu, x = load_u32(sdata, p);
+                        if (8u * tid + j < m) S[8u * tid + j] = band_word(hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu), p);
+                    }
+                }
+                v_next = spos_of(a + kBandTile);                                // (a and 128 are multiples of 8)
             }
-            const bool pure = !__syncthreads_or((int)mixed);
-            const uint32_t off = pure ? 3u : 0u, deep = pure ? 11u : 8u;
-            for (uint32_t i = tid; i < m; i += kBandThreads) {
-                const uint32_t w = S[i], q = band_pos(w) + off;
-                E[i] = make_uint2(load_u32(sdata, q), load_u32(sdata, q + 4u));   // (a halo word reads position 0's bytes: never compared)
-            }
-            auto Sf = [&](uint32_t i) { return S[i]; };
-            for (uint32_t i = kBand + tid; i < m; i += kBandThreads) ck[i - kBand] = (uint16_t)band_count(Sf, i);
             __syncthreads();
-            const uint32_t n_grp = (b - a + 63u) >> 6;
+            ZWZ_STAMP(1);
+            // ---- build
+            bool pure;
+            {
+                bool mixed = false;
+#pragma unroll 2
+                for (uint32_t i = tid; i < m; i += kBandThreads) {
+                    const uint32_t w = S[i], wp = i ? S[i - 1u] : kBandHaloWord, q = band_pos(w);
+                    const uint32_t tg = load_u32(sdata, q), tp = load_u32(sdata, band_pos(wp));
+                    E[i] = make_uint2(load_u32(sdata, q + 3u), load_u32(sdata, q + 7u));   // (a halo word reads position 0's bytes: never compared)
+                    mixed |= w != kBandHaloWord && wp != kBandHaloWord && band_hash(w) == band_hash(wp) && ((tg ^ tp) & 0xffffffu) != 0u;
+                }
+                pure = !__syncthreads_or((int)mixed);
+                if (!pure) {
+                    for (uint32_t i = tid; i < m; i += kBandThreads) { const uint32_t q = band_pos(S[i]); E[i] = make_uint2(load_u32(sdata, q), load_u32(sdata, q + 4u)); }
+                }
+            }
+            const uint32_t off = pure ? 3u : 0u, deep = pure ? 11u : 8u;
+            auto Sf = [&](uint32_t i) { return S[i]; };
+            ZWZ_STAMP(2);
+            // ---- count (thread <-> entries kBand + tid + 1024 j: the searches of a thread's entries advance together)
+            {
+                constexpr uint32_t kOwnPer = (kBandTile + kBandThreads - 1) / kBandThreads;
+                uint32_t own[kOwnPer], k[kOwnPer];
+#pragma unroll
+                for (uint32_t j = 0; j < kOwnPer; j++) { const uint32_t i = kBand + tid + kBandThreads * j; own[j] = i < m ? S[i] : kBandHaloWord; k[j] = 0; }
+                auto search_step = [&](uint32_t step) {
+                    uint32_t c[kOwnPer];
+#pragma unroll
+                    for (uint32_t j = 0; j < kOwnPer; j++) { const uint32_t t = k[j] + step; c[j] = S[kBand + tid + kBandThreads * j - (t <= kBand ? t : 0u)]; }
+#pragma unroll
+                    for (uint32_t j = 0; j < kOwnPer; j++) { const uint32_t t = k[j] + step; if (t <= kBand && band_valid(own[j], c[j])) k[j] = t; }
+                };
+                search_step(kBand);
+                bool open = false;                                              // inside a long bucket every entry has all 128: nothing to search
+#pragma unroll
+                for (uint32_t j = 0; j < kOwnPer; j++) open |= kBand + tid + kBandThreads * j < m && k[j] != kBand;
+                if (__builtin_amdgcn_ballot_w64(open) != 0) {
+#pragma unroll
+                    for (uint32_t step = kBand / 2u; step >= 1u; step >>= 1) search_step(step);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kOwnPer; j++) {
+                    const uint32_t i = kBand + tid + kBandThreads * j;
+                    if (i < m) {
+                        if (k[j] == 0u && band_first_at_max_dist(own[j], S[i - 1u])) k[j] = 1u;
+                        ck[i - kBand] = (uint16_t)k[j];
+                    }
+                }
+            }
+            __syncthreads();
+            ZWZ_STAMP(3);
+            // The halo's entries were the previous tile's last: their links (to sharers under THAT tile's word format) carry over
+            // when the format is the same; else a walk that reaches the halo starts again the slow way (band_deep).
+            const bool halo_links = a == 0u || prev_pure == pure;
+            if (tid < kBand) reinterpret_cast<uint16_t*>(S)[2u * tid + 1u] = a != 0u && halo_links ? s_halo_link[tid] : (uint16_t)kBandNoLink;
+            prev_pure = pure;
+            // ---- order: counting sort of the runs by their greatest count, longest first (runs without candidates drop out)
+            const uint32_t n_run = (b - a + 7u) >> 3;
+            uint32_t run_key = 0;
+            if (tid < n_run) {
+                const uint4 c8 = *reinterpret_cast<const uint4*>(ck + 8u * tid);   // (counts behind the tile's end are stale: masked below)
+                const uint32_t cw[4] = {c8.x, c8.y, c8.z, c8.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) if (8u * tid + j < b - a) run_key = max(run_key, (cw[j >> 1] >> (16u * (j & 1u))) & 0xffu);
+                if (run_key) atomicAdd(&s_bin[128u - run_key], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {                                                    // exclusive scan of the 128 bins
+                const uint32_t v0 = s_bin[lane], v1 = s_bin[64u + lane];
+                const uint32_t i0 = wave_scan_incl(v0), t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+                const uint32_t i1 = wave_scan_incl(v1);
+                s_bin[lane] = i0 - v0; s_bin[64u + lane] = t0 + i1 - v1;
+                if (lane == 63) s_nrun = t0 + i1;
+            }
+            __syncthreads();
+            if (tid < n_run && run_key) s_order[atomicAdd(&s_bin[128u - run_key], 1u)] = (uint16_t)tid;
+            __syncthreads();
+            ZWZ_STAMP(8);
+            const uint32_t n_act = s_nrun, n_grp = (n_act + 7u) >> 3;
             const uint32_t none = pure ? kBandKeyNonePure : kBandKeyNoneImpure;
             // ---- first pass
             for (;;) {
@@ -184,82 +361,171 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
                 if (lane == 0) g = atomicAdd(&s_grp[0], 1u);
                 g = __builtin_amdgcn_readfirstlane(g);
                 if (g >= n_grp) break;
-                const uint32_t i = kBand + 64u * g + lane;
-                const bool active = i < m;
-                const uint32_t w = S[active ? i : kBand], p = band_pos(w);
-                const uint32_t cnt = active ? (uint32_t)ck[i - kBand] : 0u;
-                const bool tail = L - p < kBandTailLook;
-                const uint32_t cntb = tail ? 0u : cnt;                         // candidates the banded loop looks at
-                const uint2 own = E[active ? i : kBand];
-                const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max_incl(cntb), 63);
-                uint32_t best = none, snap = none;
+                const uint32_t ri = 8u * g + (lane >> 3);
+                const uint32_t i = kBand + 8u * (ri < n_act ? (uint32_t)s_order[ri] : 0u) + (lane & 7u);
+                const bool active = ri < n_act && i < m;
+                const uint32_t w = S[i], p = band_pos(w);                       // (i < kBandArr whatever the lane)
+                const uint32_t cntb = active ? (uint32_t)ck[i - kBand] : 0u;
+                const uint2 own = E[i];
+                // The band, eight candidates a trip, nearest first.  A key costs eight vector instructions (two XORs, two find-first-bits,
+                // mask / mask-and-offset, minimum, shift-or with the trip's 129 - k from a scalar register) and two keys join the
+                // running maximum by one v_max3 -- picked by hand: the compiler's own choice was twelve a candidate.  Up to the
+                // smallest count among the lanes that have candidates nothing needs masking; lanes without any are kept out of
+                // it by a running maximum nothing can beat.
+                const uint32_t kmax = (ZWZ_BAND_EXP & 2) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max_incl(cntb), 63);
+                const uint32_t kmin = 128u - (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max_incl(cntb ? 128u - cntb : 0u), 63);   // (128 if nobody has any)
+                uint32_t best = cntb ? none : 0xffffffffu, snap = none;
                 const uint2* Ei = E + i;                                        // (i - k >= 0 for every lane: k <= 128 <= i)
-                for (uint32_t k0 = 0; k0 < kmax; k0 += 8u) {
-                    uint2 c[8];
+                auto key_of = [&](const uint2 c, uint32_t kc) {
+                    uint32_t t0, t1, a1, key;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(t0) : "v"(own.x ^ c.x));   // 0xffffffff for 0
+                    asm("v_ffbl_b32 %0, %1" : "=v"(t1) : "v"(own.y ^ c.y));
+                    asm("v_and_or_b32 %0, %1, %2, 32" : "=v"(a1) : "v"(t1), "s"(0x78u));   // 32 + 8 * equal bytes of the upper word; 0x78 for all four
+                    const uint32_t m8 = min(t0 & 0x78u, a1);
+                    asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(key) : "v"(m8), "s"(kc));
+                    return key;
+                };
+                const uint32_t la = L - p;
+                const bool tail = active && la < deep;                          // the word reaches past the data
+                if (__builtin_amdgcn_ballot_w64(tail) == 0) {
+                    uint32_t k0 = 0;
+                    for (; k0 + 8u <= kmin; k0 += 8u) {
+                        uint2 c[8];
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) c[j] = Ei[-(int)(k0 + j + 1u)];
+                        for (uint32_t j = 0; j < 8; j++) c[j] = Ei[-(int)(k0 + j + 1u)];
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) {
-                        const uint32_t k = k0 + j + 1u;
-                        const uint32_t key = band_key(own.x, own.y, c[j].x, c[j].y, k);
-                        best = max(best, k <= cntb ? key : 0u);
+                        for (uint32_t j = 0; j < 8; j += 2) {
+                            const uint32_t ka = key_of(c[j], 128u - k0 - j), kb = key_of(c[j + 1], 127u - k0 - j);
+                            asm("v_max3_u32 %0, %0, %1, %2" : "+v"(best) : "v"(ka), "v"(kb));
+                        }
+                        if (k0 + 8u == kShortChain) snap = best;
                     }
-                    if (k0 + 8u == kShortChain) snap = best;
+                    for (; k0 < kmax; k0 += 8u) {
+                        uint2 c[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) c[j] = Ei[-(int)(k0 + j + 1u)];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            const uint32_t key = key_of(c[j], 128u - k0 - j);
+                            best = max(best, k0 + j + 1u <= cntb ? key : 0u);
+                        }
+                        if (k0 + 8u == kShortChain) snap = best;
+                    }
+                } else {                                                        // a handful of groups per chunk: the plain loop, XORs masked to the bytes that exist
+                    const uint32_t nb = tail ? band_tail_bytes(pure, la) : 8u, m_lo = band_tail_mask(nb, 0), m_hi = band_tail_mask(nb, 1);
+                    for (uint32_t k = 1; k <= kmax; k++) {
+                        const uint2 c = Ei[-(int)k];
+                        const uint32_t key = band_key_masked(own.x, own.y, c.x, c.y, m_lo, m_hi, k);
+                        best = max(best, k <= cntb ? key : 0u);
+                        if (k == kShortChain) snap = best;
+                    }
                 }
+                if (cntb == 0u) best = none;
                 const uint32_t key32 = cntb > kShortChain ? snap : best;
                 uint32_t e128 = 0, e32 = 0, k1 = 0;
-                if (tail) {
-                    if (active) band_generic(sdata, Sf, i, cnt, L, e128, e32);
-                } else {
-                    if (best != none) {
-                        if (band_key_len(best) == 15u) k1 = band_key_k(best);
-                        else e128 = band_record(best, pure, p, band_pos(S[i - band_key_k(best)]));
-                    }
-                    if (key32 != none && band_key_len(key32) != 15u) e32 = band_record(key32, pure, p, band_pos(S[i - band_key_k(key32)]));
+                if (best != none) {
+                    if (band_key_len(best) == 15u && !tail && !(ZWZ_BAND_EXP & 1)) k1 = band_key_k(best);
+                    else e128 = band_record(best, pure, p, band_pos(S[i - band_key_k(best)]), la);
                 }
+                if (key32 != none && (tail || band_key_len(key32) != 15u)) e32 = band_record(key32, pure, p, band_pos(S[i - band_key_k(key32)]), la);
                 if (active) {
-                    ck[i - kBand] = (uint16_t)(cnt | k1 << 8);
-                    reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)(k1 ? i - k1 : kBandNoLink);   // the bucket field has done its work: now the link
                     if (k1) {
+                        ck[i - kBand] = (uint16_t)(cntb | k1 << 8);
+                        reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)(i - k1);   // the bucket field has done its work: now the link
                         if (k1 > kShortChain) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;   // final; the second pass writes the rest
                         atomicOr(&hasb[p >> 5], 1u << (p & 31u));
-                    } else if (e128) {
-                        ent[p] = make_uint2(e128, e32);
-                        atomicOr(&hasb[p >> 5], 1u << (p & 31u));
+                    } else {
+                        reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)kBandNoLink;
+                        if (e128) {
+                            ent[p] = make_uint2(e128, e32);
+                            atomicOr(&hasb[p >> 5], 1u << (p & 31u));
+                        }
                     }
                 }
             }
+            // entries of runs that were left out (no candidates anywhere in the run) link nowhere either
+            for (uint32_t i = kBand + tid; i < m; i += kBandThreads) if ((uint32_t)ck[i - kBand] == 0u) reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)kBandNoLink;
             __syncthreads();
-            // ---- second pass: positions whose nearest sharer agrees on all eight bytes
+            ZWZ_STAMP(4);
+            // ---- second pass: the flagged entries, gathered into full waves, walk their sharers (csrc/lz_band.h, band_deep).  A hop is
+            // ONE LDS round trip: an entry's word holds its position and its link, so the next entry's word and this one's
+            // eight bytes behind the compared ones are asked for together, and those eight bytes settle all but the longest matches.
+            for (uint32_t i = kBand + tid; i - tid < m; i += kBandThreads) {
+                const bool f = i < m && ((uint32_t)ck[i - kBand] >> 8) != 0u;
+                const uint64_t fm = __builtin_amdgcn_ballot_w64(f);
+                if (fm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nflag, (uint32_t)__popcll(fm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (f) flist[base + rank_in(fm)] = (uint16_t)i;
+                }
+            }
+            __syncthreads();
+            ZWZ_STAMP(9);
+            const uint32_t n_flag = s_nflag;
             for (;;) {
                 uint32_t g = 0;
                 if (lane == 0) g = atomicAdd(&s_grp[1], 1u);
                 g = __builtin_amdgcn_readfirstlane(g);
-                if (g >= n_grp) break;
-                const uint32_t i = kBand + 64u * g + lane;
-                const uint32_t c = i < m ? (uint32_t)ck[i - kBand] : 0u;
-                const uint32_t k1 = c >> 8;
-                if (k1) {
-                    const uint32_t p = band_pos(S[i]);
-                    uint32_t e128 = 0, e32 = 0;
-                    band_deep(sdata, Sf, [&](uint32_t j) { return S[j] >> 16; },
-                              [&](uint32_t j) { const uint2 e = E[j]; return (uint64_t)e.x | (uint64_t)e.y << 32; },
-                              kBand, i, c & 0xffu, k1, deep, L, e128, e32);
+                if (64u * g >= n_flag) break;
+                const bool on = 64u * g + lane < n_flag;
+                const uint32_t i = on ? (uint32_t)flist[64u * g + lane] : kBand;
+                const uint32_t c = ck[i - kBand], cnt = c & 0xffu, k1 = c >> 8;
+                const uint32_t p = band_pos(S[i]), la = L - p;
+                const uint32_t max_len = la < kMaxMatch ? la : kMaxMatch, nice = la < kNiceLen ? la : kNiceLen;
+                const uint32_t own2_lo = load_u32(sdata, p + deep), own2_hi = load_u32(sdata, p + deep + 4u);
+                uint32_t best = 0, best_pos = 0, snap = 0xffffffffu;
+                uint32_t j = on ? i - k1 : kBand;
+                uint32_t w = S[j];
+                bool walking = on, slow = false;
+                while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+                    if (walking && j < kBand && !halo_links) { slow = true; walking = false; }   // into a halo of another format: the plain walk, from the start
+                    const uint32_t q = band_pos(w), link = w >> 16, k = i - j;
+                    const bool more = link != kBandNoLink && i - link <= cnt;
+                    const uint32_t wn = S[more ? link : kBand];
+                    const uint32_t x0 = load_u32(sdata, q + deep) ^ own2_lo, x1 = load_u32(sdata, q + deep + 4u) ^ own2_hi;
+                    if (walking) {
+                        if (k > kShortChain && snap == 0xffffffffu) snap = best ? entry_pack(best, p - best_pos) : 0u;
+                        uint32_t len = (x0 | x1) ? deep + (band_ctz64(x0, x1) >> 3) : match_len_from(sdata, q, p, deep + 8u, max_len);
+                        len = len < max_len ? len : max_len;
+                        if (len > best) { best = len; best_pos = q; }
+                        walking = more && best < nice;
+                        j = link; w = wn;
+                    }
+                }
+                uint32_t e128 = entry_pack(best, p - best_pos), e32 = snap != 0xffffffffu ? snap : e128;
+                if (slow) {
+                    const uint64_t own = (uint64_t)load_u32(sdata, p + off) | (uint64_t)load_u32(sdata, p + off + 4u) << 32;
+                    band_deep(sdata, Sf, [&](uint32_t jj) { return S[jj] >> 16; },
+                              [&](uint32_t jj) { const uint2 e = E[jj]; return (uint64_t)e.x | (uint64_t)e.y << 32; },   // (halo entries only)
+                              kBand, i, cnt, k1, deep, L, own, e128, e32);
+                }
+                if (on) {
                     reinterpret_cast<uint32_t*>(ent + p)[0] = e128;
                     if (k1 <= kShortChain) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;
                 }
             }
+            __syncthreads();
+            if (tid < kBand && b < n) {                                       // (a further tile follows: this one is full, m = kBandArr)
+                const uint32_t lk = S[m - kBand + tid] >> 16;
+                s_halo_link[tid] = (uint16_t)(lk != kBandNoLink && lk >= m - kBand ? lk - (m - kBand) : kBandNoLink);
+            }
             __syncthreads();                                                  // the next tile overwrites S, E, ck and the counters
+            ZWZ_STAMP(5);
         }
+        __syncthreads();
         for (uint32_t i = tid; i < ((L + 63u) >> 6); i += kBandThreads) {
             hm[i] = (uint64_t)hasb[2 * i] | ((uint64_t)hasb[2 * i + 1] << 32);
             hasb[2 * i] = 0; hasb[2 * i + 1] = 0;
         }
+        ZWZ_STAMP(6);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 hipError_t configure_band_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlaceLdsBytes);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLdsBytes);
 }
 
@@ -273,6 +539,13 @@ hipError_t launch_sort(const DeflateArgs& a, hipStream_t s) {
     const uint32_t cus = a.cu_count ? a.cu_count : 256u;
     const uint32_t G = a.n < 2u * cus ? a.n : 2u * cus;
     hipLaunchKernelGGL(lz_sort_kernel, dim3(G), dim3(kSortThreads), 0, s, a.in, a.in_off, a.in_len, a.dense_list, a.tickets, a.sorted, a.links);
+    return hipGetLastError();
+}
+
+hipError_t launch_place(const DeflateArgs& a, hipStream_t s) {
+    const uint32_t cus = a.cu_count ? a.cu_count : 256u;
+    const uint32_t G = a.n < cus ? a.n : cus;
+    hipLaunchKernelGGL(lz_place_kernel, dim3(G), dim3(kPlaceThreads), kPlaceLdsBytes, s, a.in_len, a.dense_list, a.tickets, a.sorted);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ constexpr uint32_t kMatchListBytes = 4096 + 10240;               // bucket count
 constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163520 of 163840 (with 64 static)
 constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) words of lz_sort, sorted by (bucket, position)
 constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
+constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each
 constexpr uint32_t kBandThreads = 1024;
 constexpr uint32_t kBandTile = 5632;                             // sorted entries per tile of lz_match_band (88 groups of 64)
 constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 154 176
@@ -76,7 +77,7 @@ struct DeflateArgs {
     uint16_t* perm;            // lz_match work order of the current tile, kTile entries per chunk
     uint32_t* link_stat;       // per chunk: positions with a chain predecessor (lz_links -> lz_match's choice of work order)
     uint32_t* tickets;         // kTicketBytes of counters (kTicket*; zeroed by launch_deflate)
-    uint32_t* sorted;          // lz_sort -> lz_match_band: kSortedStride words per chunk
+    uint32_t* sorted;          // kSortedStride words per chunk: lz_sort's dest[p] (16 bits each), then lz_place's position of every sorted index
     uint32_t* dense_list;      // chunks that take the sort + band path (lz_dense_list), tickets[kTicketDenseCount] of them
     uint32_t cu_count;         // sizes the persistent grids (0: 256)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
@@ -91,7 +92,7 @@ struct InflateArgs {
 };
 
 constexpr size_t kTicketBytes = 256;
-enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4 };   // indices into DeflateArgs::tickets
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5 };   // indices into DeflateArgs::tickets
 // Chain-heavy chunk (four positions in five have a chain predecessor, lz_links' count): sort + band; else lz_match's screening pass.
 __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
 constexpr size_t kWorkspaceBytesPerChunk =
@@ -105,6 +106,7 @@ hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s);
 hipError_t configure_band_kernels();
 hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which);   // 0: by lz_links' count, 1: no chunk, 2: every chunk
 hipError_t launch_sort(const DeflateArgs& a, hipStream_t s);
+hipError_t launch_place(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_match_band(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,

@@ -21,6 +21,7 @@
 // All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -2311,7 +2312,14 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
                        a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u);
     if (which != 1u) {
         ZWZ_TRY(launch_sort(a, s));
+        ZWZ_TRY(launch_place(a, s));
         ZWZ_TRY(launch_match_band(a, s));
+        if (getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads
+            uint32_t h[64];
+            ZWZ_TRY(hipStreamSynchronize(s));
+            ZWZ_TRY(hipMemcpy(h, a.tickets, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "ZWZ_BAND_TIMES n=%u copy=%u scan=%u build=%u count=%u order=%u pass1=%u compact=%u pass2=%u flush=%u ticket=%u\n", a.n, h[16], h[17], h[18], h[19], h[24], h[20], h[25], h[21], h[22], h[23]);
+        }
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links);
