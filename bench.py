@@ -115,21 +115,41 @@ def _cpu_facts(path):
     return facts
 
 
+def _run_timed(cmd, limit_s=900):
+    """Run a command to its end; wall time between the spawn and the child's exit as wait() sees it (no polling: a
+    subprocess.run(timeout=...) wakes every 50 ms and quantised every figure of round 2), and the interval the reference
+    prints itself (main.cpp:148-155, MPI_Wtime around the operation -- what BASELINE.md section 3 asks for)."""
+    import re
+    import threading
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    killer = threading.Timer(limit_s, p.kill)
+    killer.start()
+    try:
+        out = p.stdout.read()          # (returns at EOF: the child and its ranks have closed stdout)
+        rc = p.wait()
+    finally:
+        killer.cancel()
+    wall = time.perf_counter() - t0
+    if rc != 0:
+        raise subprocess.CalledProcessError(rc, cmd)
+    m = re.findall(rb"Time Taken: ([0-9.eE+-]+) seconds", out)
+    return wall, (float(m[-1]) if m else None)
+
+
 def _time_reference(src, work, total_bytes, ranks):
     """The reference's CLI (README.md:59) as `ranks` MPI ranks; decompression is one process, a thread per shard
-    (decompression.cpp:174).  Wall time around the whole command, warm page cache."""
+    (decompression.cpp:174).  Warm page cache.  *_s is the wall clock around the whole command (process start-up, MPI
+    bootstrap and the file sort included), *_banner_s the reference's own "Time Taken"; the GB/s figures use the wall clock."""
     dst, back = os.path.join(work, "zwz%d" % ranks), os.path.join(work, "back%d" % ranks)
     cmd = [REF_MAIN] if ranks == 1 else [MPIEXEC, "-n", str(ranks), REF_MAIN]
-    t0 = time.perf_counter()
-    subprocess.run(cmd + ["compress", src, dst], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
-    t1 = time.perf_counter()
-    subprocess.run([REF_MAIN, "decompress", dst, back], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
-    t2 = time.perf_counter()
+    tc, bc = _run_timed(cmd + ["compress", src, dst])
+    td, bd = _run_timed([REF_MAIN, "decompress", dst, back])
     shutil.rmtree(dst, ignore_errors=True)
     shutil.rmtree(back, ignore_errors=True)
-    return {"compress_s": round(t1 - t0, 3), "decompress_s": round(t2 - t1, 3),
-            "compress_GBps": round(total_bytes / (t1 - t0) / 1e9, 5), "decompress_GBps": round(total_bytes / (t2 - t1) / 1e9, 5),
-            "roundtrip_GBps": round(total_bytes / (t2 - t0) / 1e9, 5)}
+    return {"bytes": total_bytes, "compress_s": round(tc, 4), "decompress_s": round(td, 4), "compress_banner_s": bc, "decompress_banner_s": bd,
+            "compress_GBps": round(total_bytes / tc / 1e9, 5), "decompress_GBps": round(total_bytes / td / 1e9, 5),
+            "roundtrip_GBps": round(total_bytes / (tc + td) / 1e9, 5)}
 
 
 def cpu_baseline(workload, host_file, n_files, file_bytes, allow_port):
@@ -165,13 +185,31 @@ def cpu_baseline(workload, host_file, n_files, file_bytes, allow_port):
             t2 = time.perf_counter()
             return {"value": round(total / (t2 - t0) / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port", "sample": sample, "host": facts,
                     "compress_GBps": round(total / (t1 - t0) / 1e9, 5), "decompress_GBps": round(total / (t2 - t1) / 1e9, 5)}
+        # K = 1, 2, 4, 8 and the box's physical cores.  The sample grows with K (n_files per rank, capped)
+        # so that no leg shrinks to a few tenths of a second; every entry states its own byte count.
         ranks = {}
-        ks = [1, 2, 4, 8] if os.path.exists(MPIEXEC) else [1]
+        ks = [1]
+        if os.path.exists(MPIEXEC):
+            ks = [1, 2, 4, 8]
+            pc = facts.get("physical_cores") or 0
+            if pc > 8 and pc <= (facts.get("cpus_allowed") or pc):
+                ks.append(pc)
+        have = n_files
         for k in ks:
-            ranks[str(k)] = _time_reference(src, work, total, k)
+            want = min(n_files * k, 8 * n_files if k <= 8 else 16 * n_files)
+            for i in range(have, want):
+                with open(os.path.join(src, "f%05d.bin" % i), "wb") as f:
+                    f.write(host_file(i))
+            have = max(have, want)
+            try:
+                ranks[str(k)] = _time_reference(src, work, have * file_bytes, k)
+            except (subprocess.CalledProcessError, OSError) as e:
+                ranks[str(k)] = {"error": str(e)}
+        sample = "first %d x K files of the workload for K ranks, at most %d (%d B %s files, same PRNG and seeds), warm page cache" % (n_files, have, file_bytes, workload)
         out = {"value": ranks["1"]["roundtrip_GBps"], "unit": "GB/s", "cores": 2, "kind": "reference", "sample": sample, "host": facts,
                "compress_GBps": ranks["1"]["compress_GBps"], "decompress_GBps": ranks["1"]["decompress_GBps"],
                "cores_note": "value = 1 MPI rank = producer + consumer thread (compression.cpp:162); ranks[K] uses 2K threads to compress and K threads (one per shard) to decompress",
+               "timer": "wall clock from spawn to the child's exit (Popen.wait, no polling); *_banner_s = the reference's own 'Time Taken' (main.cpp:148-155)",
                "ranks": ranks}
         if not os.path.exists(MPIEXEC):
             out["ranks_note"] = "no mpiexec on this box: the reference runs as an MPI singleton only"
@@ -298,10 +336,14 @@ def run_workload(args, torch, dist, codec, dev, world, rank, name):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cpu_dev if args.rehearse_on_one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time comes back to rank 0 beside the maximum: a SCALE record then shows which rank was slowest
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cpu_dev if args.rehearse_on_one_gpu else dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 3) for x in every]
+        elapsed = max(float(x.item()) for x in every)
 
     # direction split + per-kernel times (untimed extra passes, HIP events on the codec's stream)
     fence()
@@ -351,15 +393,19 @@ def run_workload(args, torch, dist, codec, dev, world, rank, name):
         comp_s, dec_s = c1 - c0, c2 - c1
         res = {
             "value": round(raw_all * args.steps / elapsed / 1e9, 3), "unit": "GB/s",
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "scaling": scaling,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_by_rank": per_rank_ms, "scaling": scaling,
             "config": {"workload": desc, "chunk_bytes": CHUNK, "max_batch_chunks": args.max_batch,
                        "parallelism": ("record-range-per-gpu x%d" if name == "one_file" else "shard-per-gpu x%d") % world,
+                       **({"scope_note": "device-resident inflate of the record ranges only.  Through the CLI (zwz_decompress_dir_ranked) ONE file is bounded by its "
+                                         "single MD5 stream (~0.65 GB/s on one host core, the reference's verification.cpp:6-30 semantics): a 64 GiB file takes "
+                                         "~105 s there whatever N is -- see DESIGN.md section 5"} if name == "one_file" else {}),
                        "timed": "inflate only" if decompress_only else "deflate + inflate"},
             "compress_GBps": round(raw_bytes / comp_s / 1e9, 3), "decompress_GBps": round(raw_bytes / dec_s / 1e9, 3),
             "payload_ratio": round(payload_bytes / raw_bytes, 4), "verified": verified,
             "stage_ms_per_pass": {k: round(v / prof_passes, 3) for k, v in stage.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/traffic_%s.json (a builder-run rocprofv3 PMC pass, 2*FETCH_SIZE + WRITE_SIZE per launch; not measured in this run)" % name if traffic is not None else None,
                          "algorithmic_bytes_per_launch": int(algo_per_launch), "launch_ms": round(dom_ms, 4),
                          # whole directions: algorithmic bytes (raw + payload) / wall time of the direction
                          "compress_frac_of_8TBps": round((raw_bytes + payload_bytes) / comp_s / 1e9 / HBM_PEAK_GBS, 5),
@@ -404,7 +450,20 @@ def main():
     if not os.path.exists(zwz.LIB_PATH) and rank == 0:      # a checkout that never ran build(): artefacts are git-ignored
         import __graft_entry__
         __graft_entry__.build()
+    comm = None
     if world > 1:
+        # First collective of the job, and a self-check of it: every rank contributes a one and its device index.  A SCALE
+        # record then says how many ranks the backend (RCCL under "nccl") really joined and where each one ran.
+        cdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([local, torch.cuda.current_device()], dtype=torch.int64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        comm = {"backend": dist.get_backend(), "ranks_seen": int(ones.item()), "rccl_ranks_seen": int(ones.item()) if dist.get_backend() == "nccl" else None,
+                "devices_by_rank": [int(x[1].item()) for x in every], "device_name": torch.cuda.get_device_name(local)}
+        if comm["ranks_seen"] != world:
+            raise SystemExit("bench.py: the all-reduce saw %d of %d ranks" % (comm["ranks_seen"], world))
         dist.barrier()
     codec = zwz.Codec(local, args.max_batch)
 
@@ -416,6 +475,9 @@ def main():
                 "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
                 "vs_baseline": None, "dtype": "u8", "data": "synthetic (own splitmix64 PRNG, seeds in tests/workloads.py)"}
+        if comm is not None:
+            line["comm"] = comm
+            line["rccl_ranks_seen"] = comm["rccl_ranks_seen"]
         for k, v in head.items():
             line.setdefault(k, v)
         for nm, r in zip(names[1:], results[1:]):

@@ -74,7 +74,7 @@ int links_self_test(zwz_ctx* c) {
     if (e == hipSuccess) e = hipMemsetAsync(d_links, 0xa5, K * (size_t)kLinkStride * sizeof(uint16_t), c->stream);
     DeflateArgs a{};
     a.in = d_in; a.in_off = d_off; a.in_len = d_len; a.n = K; a.links = d_links; a.link_stat = d_stat; a.cu_count = 3;
-    a.sorted = d_sorted; a.dense_list = d_list; a.tickets = d_tickets;
+    a.sorted = d_sorted; a.dense_list = d_list; a.sparse_list = d_list; a.tickets = d_tickets;   // (every chunk goes onto the dense list here)
     if (e == hipSuccess) e = launch_links_only(a, c->stream);
     std::vector<uint16_t> got(K * (size_t)kLinkStride);
     uint32_t stat[K] = {};
@@ -368,6 +368,7 @@ void carve_workspace(zwz_ctx* c, DeflateArgs& a) {
     a.tickets = reinterpret_cast<uint32_t*>(take(kTicketBytes));
     a.sorted = reinterpret_cast<uint32_t*>(take(n * kSortedStride * sizeof(uint32_t)));
     a.dense_list = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
+    a.sparse_list = reinterpret_cast<uint32_t*>(take(n * sizeof(uint32_t)));
     a.cu_count = c->cu_count;
     a.info = reinterpret_cast<ChunkInfo*>(take(n * sizeof(ChunkInfo)));
     a.blocks = reinterpret_cast<BlockInfo*>(take(n * kMaxBlocks * sizeof(BlockInfo)));

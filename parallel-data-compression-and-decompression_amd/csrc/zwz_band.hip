@@ -2,7 +2,7 @@
 // chain walk.  Replaces, for those chunks, what lz_match's walk did with two dependent LDS gathers per candidate
 // (consumer()'s longest_match, compression.cpp:119-131); the arithmetic and its proof of equivalence are csrc/lz_band.h.
 //
-//   lz_dense_list  one thread / chunk   chunks whose lz_links count says "chain-heavy" -> a list
+//   lz_dense_list  one wave / chunk     a sample of the chunk's trigrams says "chain-heavy" or not -> two lists
 //   lz_sort        one WG / chunk       positions sorted by (hash bucket, position): histogram, scan, and a ranking pass by
 //                                       ONE wave -- ds_add_rtn serves same-address lanes in lane order, the property lz_links
 //                                       already stands on -- whose results go out as (bucket << 16 | position) words
@@ -32,18 +32,74 @@
 namespace zwz {
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lz_dense_list_kernel(const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ link_stat, uint32_t n,
-                                                            uint32_t* __restrict__ list, uint32_t* __restrict__ tickets, uint32_t force) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-    if (c >= n) return;
-    const uint32_t L = in_len[c];
-    const bool dense = force == 2u ? L != 0u : (force == 1u ? false : (L != 0u && chunk_is_dense(link_stat[c], L)));
-    const uint64_t m = __builtin_amdgcn_ballot_w64(dense);
-    if (m == 0) return;
-    uint32_t base = 0;
-    if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&tickets[kTicketDenseCount], (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
-    if (dense) list[base + rank_in(m)] = c;
+// lz_dense_list: a wave per chunk hashes the chunk's first kDenseSample trigrams into a 32 Ki-bit set (LDS) and counts the ones
+// whose bucket was taken already.  Chain-heavy chunks get kDenseMark in link_stat[], the others 0 (for lz_links to count in);
+// lz_lists turns the marks into the two lists.
+constexpr uint32_t kDenseThreads = 256;
+__global__ __launch_bounds__(kDenseThreads) void lz_dense_list_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+                                                                      const uint32_t* __restrict__ in_len, uint32_t n, uint32_t* __restrict__ link_stat,
+                                                                      uint32_t force /* 2: every chunk is chain-heavy */) {
+    __shared__ uint32_t s_set[kDenseThreads / 64][1024];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* set = s_set[wave];
+    // persistent: a wave takes chunks wave-id, + all waves, ... (a workgroup per four chunks spent more time being dispatched than working)
+    for (uint32_t c = blockIdx.x * (kDenseThreads / 64u) + wave; c < n; c += gridDim.x * (kDenseThreads / 64u)) {
+        const uint32_t L = in_len[c];
+        bool dense = force == 2u && L != 0u;
+        if (!dense && L >= kMinMatch) {
+            for (uint32_t i = lane; i < 1024u; i += 64u) set[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t* d32 = reinterpret_cast<const uint32_t*>(in + in_off[c]);       // 16-byte aligned; readable to L rounded up to 16
+            const uint32_t sampled = min(L - (kMinMatch - 1u), kDenseSample), nd = ((L + 15u) & ~15u) >> 2;
+            uint32_t repeats = 0;
+            static_assert(kDenseSample == 2048, "eight trips of 256 positions, their loads asked for together");
+            uint32_t w0[8], w1[8];                                                      // four positions a lane a trip: a dword and its successor
+#pragma unroll
+            for (uint32_t t = 0; t < 8; t++) {
+                const uint32_t i = 64u * t + lane;
+                w0[t] = 256u * t < sampled && i < nd ? d32[i] : 0u; w1[t] = 256u * t < sampled && i + 1u < nd ? d32[i + 1u] : 0u;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < 8; t++) {
+                if (256u * t >= sampled) break;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t x = j ? __builtin_amdgcn_alignbyte(w1[t], w0[t], j) : w0[t];
+                    const uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
+                    const bool live = 256u * t + 4u * lane + j < sampled;
+                    uint32_t old = 0;
+                    if (live) old = atomicOr(&set[h >> 5], 1u << (h & 31u));            // (same-word lanes are served one after the other: each sees the earlier ones' bits)
+                    repeats += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && ((old >> (h & 31u)) & 1u)));
+                }
+            }
+            dense = sample_is_dense(repeats, sampled);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if (lane == 0) link_stat[c] = dense ? kDenseMark : 0u;
+    }
+}
+
+// The two lists, each in chunk order (one workgroup; appended by atomics their order was arbitrary, and lz_links' workgroups,
+// which take list entries w, w + G, ..., ended up with uneven shares of config 2's full and 4-byte chunks).
+__global__ __launch_bounds__(1024) void lz_lists_kernel(const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ link_stat, uint32_t n,
+                                                        uint32_t* __restrict__ dense_list, uint32_t* __restrict__ sparse_list, uint32_t* __restrict__ tickets) {
+    __shared__ uint32_t s_d[16], s_s[16];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    uint32_t nd = 0, ns = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024u) {
+        const uint32_t c = c0 + tid;
+        const bool live = c < n && in_len[c] != 0u, dense = live && link_stat[c] == kDenseMark, sparse = live && !dense;
+        const uint64_t md = __builtin_amdgcn_ballot_w64(dense), ms = __builtin_amdgcn_ballot_w64(sparse);
+        if (lane == 0) { s_d[wave] = (uint32_t)__popcll(md); s_s[wave] = (uint32_t)__popcll(ms); }
+        __syncthreads();
+        uint32_t bd = nd, bs = ns, td = 0, ts = 0;
+        for (uint32_t w = 0; w < 16u; w++) { bd += w < wave ? s_d[w] : 0u; bs += w < wave ? s_s[w] : 0u; td += s_d[w]; ts += s_s[w]; }
+        if (dense) dense_list[bd + rank_in(md)] = c;
+        if (sparse) sparse_list[bs + rank_in(ms)] = c;
+        nd += td; ns += ts;
+        __syncthreads();
+    }
+    if (tid == 0) { tickets[kTicketDenseCount] = nd; tickets[kTicketSparseCount] = ns; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,25 +188,31 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         // ranking: positions in order, 64 a step, by ONE wave: the returning add hands same-bucket lanes their slots in lane order
         // (= position order), steps follow one another in program order.
         if (wave == 0) {
-            const uint32_t steps = (n + 63u) >> 6;
+            // Whole trips of eight steps run without a single test (every lane has a position: guarded per lane, the loop was
+            // mostly exec-mask bookkeeping); the next trip's hashes are on their way while this one ranks.
+            const uint32_t full = n >> 9;                                       // trips of 512 positions
             uint32_t hv[8];
-            auto ask = [&](uint32_t s0, uint32_t* h8) {
+            auto ask = [&](uint32_t t, uint32_t* h8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) { const uint32_t p = (s0 + j) * 64u + lane; h8[j] = p < n ? (uint32_t)hb[p] : 0xffffffffu; }
+                for (uint32_t j = 0; j < 8; j++) h8[j] = hb[(t * 8u + j) * 64u + lane];
             };
-            ask(0u, hv);
-            for (uint32_t s0 = 0; s0 < steps; s0 += 8u) {
+            if (full) ask(0u, hv);
+            for (uint32_t t = 0; t < full; t++) {
                 uint32_t hn[8], old[8];
-                ask(s0 + 8u, hn);                                               // the next trip's hashes are on their way while this trip ranks
+                if (t + 1u < full) ask(t + 1u, hn);
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) old[j] = hv[j] != 0xffffffffu ? atomicAdd(&tab[hv[j] >> 1], (hv[j] & 1u) ? 0x10000u : 1u) : 0u;
+                for (uint32_t j = 0; j < 8; j++) old[j] = atomicAdd(&tab[hv[j] >> 1], 1u << ((hv[j] & 1u) << 4));
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t p = (s0 + j) * 64u + lane;
-                    if (hv[j] != 0xffffffffu) out[p] = (uint16_t)((hv[j] & 1u) ? old[j] >> 16 : old[j]);
-                }
+                for (uint32_t j = 0; j < 8; j++) out[(t * 8u + j) * 64u + lane] = (uint16_t)(old[j] >> ((hv[j] & 1u) << 4));
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) hv[j] = hn[j];
+            }
+            for (uint32_t p = full * 512u + lane; p - lane < n; p += 64u) {     // the ragged end, a step at a time
+                if (p < n) {
+                    const uint32_t h = hb[p];
+                    const uint32_t old = atomicAdd(&tab[h >> 1], 1u << ((h & 1u) << 4));
+                    out[p] = (uint16_t)(old >> ((h & 1u) << 4));
+                }
             }
         }
     }
@@ -529,9 +591,11 @@ hipError_t configure_band_kernels() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLdsBytes);
 }
 
-// which: 0 = by lz_links' count (production), 1 = no chunk, 2 = every chunk (tests).
+// which: 0 = by a sample of each chunk (production), 2 = every chunk is chain-heavy (tests).
 hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which) {
-    hipLaunchKernelGGL(lz_dense_list_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a.in_len, a.link_stat, a.n, a.dense_list, a.tickets, which);
+    const uint32_t cus = a.cu_count ? a.cu_count : 256u, want = (a.n + kDenseThreads / 64u - 1u) / (kDenseThreads / 64u);
+    hipLaunchKernelGGL(lz_dense_list_kernel, dim3(want < 8u * cus ? want : 8u * cus), dim3(kDenseThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.link_stat, which);
+    hipLaunchKernelGGL(lz_lists_kernel, dim3(1), dim3(1024), 0, s, a.in_len, a.link_stat, a.n, a.dense_list, a.sparse_list, a.tickets);
     return hipGetLastError();
 }
 

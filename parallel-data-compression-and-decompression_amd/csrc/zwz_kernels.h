@@ -79,6 +79,7 @@ struct DeflateArgs {
     uint32_t* tickets;         // kTicketBytes of counters (kTicket*; zeroed by launch_deflate)
     uint32_t* sorted;          // kSortedStride words per chunk: lz_sort's dest[p] (16 bits each), then lz_place's position of every sorted index
     uint32_t* dense_list;      // chunks that take the sort + band path (lz_dense_list), tickets[kTicketDenseCount] of them
+    uint32_t* sparse_list;     // the others that have any bytes: lz_links' work, tickets[kTicketSparseCount] of them
     uint32_t cu_count;         // sizes the persistent grids (0: 256)
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
@@ -92,11 +93,17 @@ struct InflateArgs {
 };
 
 constexpr size_t kTicketBytes = 256;
-enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5 };   // indices into DeflateArgs::tickets
-// Chain-heavy chunk (four positions in five have a chain predecessor, lz_links' count): sort + band; else lz_match's screening pass.
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6 };   // indices into DeflateArgs::tickets
+// lz_match on its own (ZWZ_MATCH=walk): a chunk four of whose five positions have a chain predecessor (lz_links' count) takes the sorted walk.
 __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
+// With the band kernels: lz_dense_list looks at a chunk's first kDenseSample positions and calls it chain-heavy -- sort + band --
+// when one in five of them falls into a bucket an earlier one of the sample fell into (incompressible bytes: one in thirty;
+// the text corpus: two in five); its mark in link_stat[] tells lz_match which chunks are not its own.  Either path gives the
+// same records: the choice is speed only.
+constexpr uint32_t kDenseSample = 2048, kDenseMark = 0xffffffffu;
+__host__ __device__ inline bool sample_is_dense(uint32_t repeats, uint32_t sampled) { return repeats * 5u >= sampled; }
 constexpr size_t kWorkspaceBytesPerChunk =
-    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) + (size_t)kSortedStride * 4 + 4 +
+    (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) + (size_t)kSortedStride * 4 + 8 +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));
 
 hipError_t configure_kernels();
@@ -104,7 +111,7 @@ hipError_t probe_exchange_order(hipStream_t s, bool* holds);   // see exchange_o
 hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* stage_events);
 hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s);
 hipError_t configure_band_kernels();
-hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which);   // 0: by lz_links' count, 1: no chunk, 2: every chunk
+hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which);   // 0: by a sample of each chunk, 2: every chunk is chain-heavy
 hipError_t launch_sort(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_place(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_match_band(const DeflateArgs& a, hipStream_t s);

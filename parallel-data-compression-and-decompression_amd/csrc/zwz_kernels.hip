@@ -82,28 +82,35 @@ constexpr uint32_t kLinksNoHash = 0;               // bucket of a position witho
 // of the kernel.)
 __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint16_t* __restrict__ links,
-                                                                 uint32_t* __restrict__ link_stat /* zeroed by the launcher */, uint32_t n) {
+                                                                 uint32_t* __restrict__ link_stat /* zeroed by the launcher */, uint32_t n_all,
+                                                                 const uint32_t* __restrict__ list /* null: every chunk; else the chunks to link ... */,
+                                                                 const uint32_t* __restrict__ list_n /* ... and how many there are */) {
     // typed LDS arrays: a generic/volatile pointer here turns every access into a flat_* op with a
     // vmcnt(0) wait behind it (measured: 870 cycles per 64-position step)
     extern __shared__ __attribute__((aligned(16))) uint16_t head[];          // 32768 32-bit buckets + 16 spare bytes
     constexpr uint32_t kHeadBytes = 131072u;
     uint16_t* hbuf = head + (kHeadBytes + 16u) / 2u;                        // 2 x kLinksBlock 32-bit entries: bucket addresses in, links out
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t G = gridDim.x;                                            // <= n: every workgroup has a first chunk
+    const uint32_t G = gridDim.x;
     // A cursor: block k of the chunk c = blockIdx.x + j G, the g-th block of this workgroup's stream (the input register sets
     // rotate with g mod 3, the two hand-over buffers alternate with g).  The stream ends on a multiple of three hand-overs;
     // blocks past its end hash to the no-trigram bucket and are never inserted or written out.
     // All of it is wave-uniform (scalar loads, scalar registers).
     struct Cursor { uint32_t c, j, k, g, L, n_blocks; const uint8_t* data; uint16_t* lk; };
-    const uint8_t* const data0 = in + in_off[blockIdx.x];                    // any readable 16 bytes, for requests past the last chunk
-    uint16_t* const lk_spare = links + (size_t)blockIdx.x * kLinkStride + (kLinkStride - 1u);   // position 65 535 does not exist: nobody's link
+    // (with a list -- lz_dense_list's sparse chunks -- the workgroups' stream runs over list entries: c is an index into it)
+    const uint32_t n = list ? *list_n : n_all;
+    if (blockIdx.x >= n) return;                                             // (more workgroups than chunks: the whole workgroup leaves)
+    auto cid = [&](uint32_t c) { return list ? list[c] : c; };
+    const uint8_t* const data0 = in + in_off[cid(blockIdx.x)];               // any readable 16 bytes, for requests past the last chunk
+    uint16_t* const lk_spare = links + (size_t)cid(blockIdx.x) * kLinkStride + (kLinkStride - 1u);   // position 65 535 does not exist: nobody's link
     auto enter = [&](Cursor& q) {                                            // settle on chunk q.c or the next one with any bytes
         for (;;) {
             if (q.c >= n) { q.L = 0; q.n_blocks = 0xffffffffu; q.data = data0; q.lk = nullptr; return; }   // past the end: stays here
-            q.L = in_len[q.c];
+            const uint32_t ch = cid(q.c);
+            q.L = in_len[ch];
             q.n_blocks = (q.L + kLinksBlock - 1u) / kLinksBlock;
-            q.data = in + in_off[q.c];                                       // 16-byte aligned (API contract)
-            q.lk = links + (size_t)q.c * kLinkStride;
+            q.data = in + in_off[ch];                                        // 16-byte aligned (API contract)
+            q.lk = links + (size_t)ch * kLinkStride;
             if (q.n_blocks) return;
             q.c += G; q.j++;
         }
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         __builtin_amdgcn_s_setprio(3);              // the inserter shares its SIMD with two feeder waves and is the critical path
         uint32_t g = 0;
         for (uint32_t c = blockIdx.x, j = 0; c < n; c += G, j++) {
-            const uint32_t L = in_len[c];
+            const uint32_t L = in_len[cid(c)];
             const uint32_t n_blocks = (L + kLinksBlock - 1u) / kLinksBlock;
             for (uint32_t k = 0; k < n_blocks; k++, g++) {
                 insert_block(k, L, (j + 1u) << 16, g & 1u);
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     } else {
         auto chunk_done = [&](const Cursor& q) {    // the feeder waves add up a chunk's linked positions: lz_match picks its work order by it
             for (uint32_t d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d);
-            if (lane == 0 && linked) atomicAdd(&link_stat[q.c], linked);
+            if (lane == 0 && linked) atomicAdd(&link_stat[cid(q.c)], linked);
             linked = 0;
         };
         bool first_trip = true;                     // fl sits on the block the inserter has just finished, except before the first trip
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
-    if (L == 0 || band == 2u || (band == 1u && chunk_is_dense(link_stat[chunk], L))) return;
+    if (L == 0 || band == 2u || (band == 1u && link_stat[chunk] == kDenseMark)) return;
     uint8_t* sdata = smem;
     uint16_t* slink = reinterpret_cast<uint16_t*>(smem + kMatchDataBytes);
     uint32_t* s_has = reinterpret_cast<uint32_t*>(smem + kMatchDataBytes + kMatchLinkBytes);      // 2 KiB: has128 bits of a tile
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     }
     // chain-heavy data (four of five positions have a chain predecessor: text) takes the sorted work order, sparse
     // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
-    const bool sorted_order = chunk_is_dense(link_stat[chunk], L);  // workgroup-uniform
+    const bool sorted_order = band == 0u && chunk_is_dense(link_stat[chunk], L);  // workgroup-uniform (with the band kernels about, what gets here is sparse)
     for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
     uint32_t org = 0;
     ZWZ_PREFETCH(0u)
@@ -2270,15 +2277,22 @@ hipError_t probe_exchange_order(hipStream_t s, bool* holds) {
 
 // lz_links: a workgroup per CU (a.cu_count; the self-test passes fewer to make every workgroup cross chunk boundaries), chunks
 // strided over them; an epoch is 16 bits, so a launch covers at most 65 535 chunks per workgroup
-static hipError_t launch_links(const DeflateArgs& a, hipStream_t s) {
-    ZWZ_TRY(hipMemsetAsync(a.link_stat, 0, (size_t)a.n * sizeof(uint32_t), s));
+static hipError_t launch_links(const DeflateArgs& a, hipStream_t s, bool listed) {
     const uint32_t cus = a.cu_count ? a.cu_count : 256u;
+    if (listed) {   // lz_dense_list's sparse chunks (link_stat is its array of marks: a sparse chunk's starts at 0)
+        const uint32_t G = a.n < cus ? a.n : cus;
+        if ((uint64_t)a.n > 65535ull * G) return hipErrorInvalidValue;      // (an epoch is 16 bits; max_batch keeps slices far below)
+        hipLaunchKernelGGL(lz_links_kernel, dim3(G), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.link_stat, a.n,
+                           a.sparse_list, a.tickets + kTicketSparseCount);
+        return hipGetLastError();
+    }
+    ZWZ_TRY(hipMemsetAsync(a.link_stat, 0, (size_t)a.n * sizeof(uint32_t), s));
     for (uint32_t done = 0; done < a.n;) {
         const uint32_t left = a.n - done, G = left < cus ? left : cus;
         const uint64_t cap = 65535ull * G;
         const uint32_t m = left < cap ? left : (uint32_t)cap;
         hipLaunchKernelGGL(lz_links_kernel, dim3(G), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off + done, a.in_len + done,
-                           a.links + (size_t)done * kLinkStride, a.link_stat + done, m);
+                           a.links + (size_t)done * kLinkStride, a.link_stat + done, m, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         done += m;
     }
     return hipGetLastError();
@@ -2287,7 +2301,7 @@ static hipError_t launch_links(const DeflateArgs& a, hipStream_t s) {
 // lz_links alone over a batch (zwz_ctx_create's known-answer test of the hand-scheduled kernel)
 hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    return launch_links(a, s);
+    return launch_links(a, s, false);
 }
 
 hipError_t configure_kernels() {
@@ -2302,12 +2316,16 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (a.n == 0) return hipSuccess;
     ZWZ_TRY(hipMemsetAsync(a.tickets, 0, kTicketBytes, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[0], s));
-    ZWZ_TRY(launch_links(a, s));
-    if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
-    // chain-heavy chunks: positions sorted by (bucket, position), then the banded search (zwz_band.hip); the rest: lz_match's
-    // screening pass over the links.  ZWZ_MATCH=walk sends every chunk through lz_match, =band every chunk through the band.
+    // Chain-heavy chunks (lz_dense_list: a sample of each chunk's trigrams): positions sorted by (bucket, position), then the banded
+    // search (zwz_band.hip).  The rest: chain links, then lz_match's screening pass over them.  ZWZ_MATCH=walk sends every chunk
+    // through links + lz_match (its sorted walk included), =band every chunk through the band.
     const uint32_t which = [] { const char* e = getenv("ZWZ_MATCH"); return e && !strcmp(e, "walk") ? 1u : e && !strcmp(e, "band") ? 2u : 0u; }();   // (read per launch: tests flip it)
-    ZWZ_TRY(launch_dense_list(a, s, which));
+    if (which == 1u) ZWZ_TRY(launch_links(a, s, false));
+    else {
+        ZWZ_TRY(launch_dense_list(a, s, which));
+        ZWZ_TRY(launch_links(a, s, true));
+    }
+    if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u);
     if (which != 1u) {
