@@ -137,14 +137,18 @@ def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=
         with tempfile.NamedTemporaryFile(prefix="zwz_list_r%d_" % rank, suffix=".txt", delete=False) as f:
             f.write(listing)
             local_record = f.name
+        failure = None
         try:
             shard_dir = output_path
             if gather and world > 1 and rank != 0:
                 shard_dir = tempfile.mkdtemp(prefix="zwz_shard_r%d_" % rank)
-            if rank < count_fn(local_record):                       # main.cpp:44-51
-                compress_fn(source_path, shard_dir, local_record, rank, world)
-            else:
-                print("Rank: %d - No file to compress" % rank, file=out)
+            try:
+                if rank < count_fn(local_record):                   # main.cpp:44-51
+                    compress_fn(source_path, shard_dir, local_record, rank, world)
+                else:
+                    print("Rank: %d - No file to compress" % rank, file=out)
+            except Exception as e:      # a failed rank still joins the collectives below: its peers have no time-out there
+                failure = e
             if gather and world > 1:
                 path = os.path.join(shard_dir, "compressed_%d.zwz" % rank)
                 blob = open(path, "rb").read() if os.path.exists(path) else b""
@@ -159,10 +163,20 @@ def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=
     else:
         # The reference decodes on rank 0 only (main.cpp:61-68); here every rank takes its share: whole shards round-robin,
         # or record ranges of a shard when there are fewer shards than ranks.
-        decompress_fn(source_path, output_path, rank, world, allgather_u64 if world > 1 else None)
+        failure = None
+        try:
+            decompress_fn(source_path, output_path, rank, world, allgather_u64 if world > 1 else None)
+        except Exception as e:          # (zwz_decompress_dir_ranked itself carries a rank's failure through its exchanges)
+            failure = e
 
     if world > 1:
-        dist.barrier()
+        # MPI_Barrier (main.cpp:144) and the job's status in one: every rank learns whether any rank failed
+        bad = allgather_u64([1 if failure is not None else 0])
+        if failure is None and any(bad):
+            failure = RuntimeError("rank(s) %s failed" % ", ".join(str(r) for r, b in enumerate(bad) if b))
+    if failure is not None:
+        print("zwz: %s" % failure, file=sys.stderr)
+        rc = 2
     if rank == 0:                                                    # main.cpp:148-155
         print("========================================\nOperation: %s\nProcessor Count: %d\nTime Taken: %g seconds\n"
               "========================================" % (operation, world, time.perf_counter() - start), file=out)

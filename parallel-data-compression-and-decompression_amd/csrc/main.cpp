@@ -111,7 +111,34 @@ struct Rendezvous {
 
     std::string path(const std::string& tail) const { return dir + "/" + stem + "_" + tail; }
 
-    void hello() { if (rank != 0) write_atomic(path("here_" + std::to_string(rank) + "_" + nonce), nonce + "\n"); }
+    // a rank announces itself once its codec context exists (or has failed): the second line says whether it could join an RCCL communicator
+    void hello(bool healthy) { if (rank != 0) write_atomic(path("here_" + std::to_string(rank) + "_" + nonce), nonce + "\n" + (healthy ? "ok" : "bad") + "\n"); }
+
+    // rank 0, before it publishes anything: wait for every rank's announcement (MPI_Barrier, main.cpp:41) and learn whether all of them
+    // are healthy.  The choice between RCCL and marker files is made HERE, once, for the whole job -- a rank that decided alone
+    // left the others waiting inside ncclCommInitRank or a collective.  false: some rank never showed up (then: files).
+    bool gather(bool& all_healthy) {
+        const double t0 = now_s();
+        for (;;) {
+            std::vector<bool> have((size_t)world, false);
+            have[0] = true; all_healthy = true;
+            for (const std::string& n : names_with_prefix(dir, stem + "_here_")) {
+                const std::string rest = n.substr(stem.size() + 6);               // "<rank>_<nonce>"
+                const size_t us = rest.find('_');
+                if (us == std::string::npos) continue;
+                const int r = atoi(rest.substr(0, us).c_str());
+                if (r <= 0 || r >= world) continue;
+                std::string content;
+                if (!read_all(dir + "/" + n, content)) continue;
+                const std::vector<std::string> ls = lines_of(content);
+                have[(size_t)r] = true;
+                if (ls.size() < 2 || ls[1] != "ok") all_healthy = false;
+            }
+            if (std::all_of(have.begin(), have.end(), [](bool b) { return b; })) return true;
+            if (now_s() - t0 > timeout_s) { all_healthy = false; return false; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
 
     // rank 0: (re)publish payload + every announced nonce; true once every rank has announced itself at least once
     bool publish() {
@@ -131,16 +158,6 @@ struct Rendezvous {
             if (write_atomic(path("list_" + nonce), content)) seen = nonces;
         }
         return std::all_of(have.begin(), have.end(), [](bool b) { return b; });
-    }
-
-    // rank 0: publish and wait until every rank of the launch has announced itself (MPI_Barrier, main.cpp:41)
-    bool publish_to_all() {
-        const double t0 = now_s();
-        while (!publish()) {
-            if (now_s() - t0 > timeout_s) return false;
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        }
-        return true;
     }
 
     // rank > 0: wait for a publication that names this process
@@ -215,6 +232,7 @@ struct Rccl {
     }
     static bool unhex(const std::string& s, void* p, size_t n) {
         if (s.size() != 2 * n) return false;
+        for (char c : s) if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f'))) return false;
         auto v = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
         for (size_t i = 0; i < n; i++) static_cast<unsigned char*>(p)[i] = (unsigned char)(v(s[2 * i]) << 4 | v(s[2 * i + 1]));
         return true;
@@ -249,6 +267,31 @@ struct Rccl {
             char* send = static_cast<char*>(d) + one * (size_t)world;
             return hipMemcpy(send, mine, one, hipMemcpyHostToDevice) == hipSuccess && ncclAllGather(send, d, count, ncclUint64, comm, stream) == ncclSuccess &&
                    hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(all, d, one * (size_t)world, hipMemcpyDeviceToHost) == hipSuccess; }) ? 0 : -1;
+    }
+    // "a final gather of per-shard .zwz blobs" (north star; the reference leaves every rank's shard where the rank wrote it): sizes by
+    // all-gather, then one grouped send per rank and the matching receives on rank 0.  blobs[r] is filled on rank 0 only.
+    bool gather_blobs(const std::string& mine, std::vector<std::string>& blobs) {
+        std::vector<uint64_t> sizes((size_t)world);
+        const uint64_t my_size = mine.size();
+        if (allgather(&my_size, sizes.data(), 1) != 0) return false;
+        std::vector<void*> bufs((size_t)world, nullptr);
+        bool ok = true;
+        auto free_all = [&] { for (void* p : bufs) if (p) (void)hipFree(p); };
+        if (rank == 0) { for (int r = 1; r < world && ok; r++) if (sizes[(size_t)r]) ok = hipMalloc(&bufs[(size_t)r], (size_t)sizes[(size_t)r]) == hipSuccess; }
+        else if (my_size) ok = hipMalloc(&bufs[(size_t)rank], (size_t)my_size) == hipSuccess && hipMemcpy(bufs[(size_t)rank], mine.data(), (size_t)my_size, hipMemcpyHostToDevice) == hipSuccess;
+        // (a rank that could not allocate still enters the group with what it has: the peers' sends and receives must pair up or fail together)
+        if (ncclGroupStart() != ncclSuccess) { free_all(); return false; }
+        if (rank == 0) { for (int r = 1; r < world; r++) if (sizes[(size_t)r] && bufs[(size_t)r]) ok = ncclRecv(bufs[(size_t)r], (size_t)sizes[(size_t)r], ncclChar, r, comm, stream) == ncclSuccess && ok; }
+        else if (my_size && bufs[(size_t)rank]) ok = ncclSend(bufs[(size_t)rank], (size_t)my_size, ncclChar, 0, comm, stream) == ncclSuccess && ok;
+        ok = ncclGroupEnd() == ncclSuccess && ok;
+        ok = hipStreamSynchronize(stream) == hipSuccess && ok;
+        blobs.assign((size_t)world, std::string());
+        if (rank == 0) {
+            blobs[0] = mine;
+            for (int r = 1; r < world && ok; r++) if (sizes[(size_t)r]) { blobs[(size_t)r].resize((size_t)sizes[(size_t)r]); ok = hipMemcpy(&blobs[(size_t)r][0], bufs[(size_t)r], (size_t)sizes[(size_t)r], hipMemcpyDeviceToHost) == hipSuccess; }
+        }
+        free_all();
+        return ok;
     }
     int worst_status(int rc) {                                      // barrier + every rank learns whether any rank failed
         int64_t v = rc != 0;
@@ -311,7 +354,6 @@ int main(int argc, char* argv[]) {
         const double t0 = now_s();
         struct stat st {};
         while (stat(output_path.c_str(), &st) != 0 && now_s() - t0 < rv.timeout_s) std::this_thread::sleep_for(std::chrono::milliseconds(5));
-        rv.hello();
     }
 
     int device_count = 0;
@@ -324,16 +366,25 @@ int main(int argc, char* argv[]) {
     if (trace) fprintf(stderr, "zwz: context ready at %.3f s\n", since());
     if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
-    // ---- RCCL communicator (see struct Rccl): its id rides on the handshake's publication
+    // ---- RCCL communicator (see struct Rccl): its id rides on the handshake's publication -- and only if EVERY rank can join:
+    // each rank says so in its announcement, rank 0 reads them all before it publishes (Rendezvous::gather), so either all
+    // ranks find an id and enter ncclCommInitRank, or none does and all keep to the marker files.
     Rccl nc;
     const char* comm_env = getenv("ZWZ_COMM");
     const bool want_rccl = rc == ZWZ_OK && (world_size > 1 ? device_count >= world_size : false) && !(comm_env && !strcmp(comm_env, "files"));
     const bool force_rccl = rc == ZWZ_OK && comm_env && !strcmp(comm_env, "rccl");          // (also with one rank: exercises the path on a 1-GPU box)
+    if (world_size > 1 && world_rank != 0) rv.hello(want_rccl || force_rccl);
+    bool all_here = true, all_healthy = true;
+    if (world_size > 1 && world_rank == 0) all_here = rv.gather(all_healthy);               // (the ranks wait in accept() meanwhile, as they did for the file sort)
     std::string nccl_hex;
-    if (world_rank == 0 && (want_rccl || force_rccl)) {
-        ncclUniqueId id;
-        if (ncclGetUniqueId(&id) == ncclSuccess) nccl_hex = Rccl::hex(&id, sizeof id);
-    }
+    auto make_id = [&] {        // rank 0, at the moment it publishes: its own state counts too (a failed file sort means no communicator)
+        if (world_rank == 0 && rc == ZWZ_OK && (want_rccl || force_rccl) && all_here && all_healthy) {
+            ncclUniqueId id;
+            if (ncclGetUniqueId(&id) == ncclSuccess) nccl_hex = Rccl::hex(&id, sizeof id);
+        }
+        if (world_rank == 0 && world_size > 1 && trace) fprintf(stderr, "zwz: rank 0: %s for this job (%s)\n", nccl_hex.empty() ? "marker files" : "RCCL",
+                                                                 !all_here ? "a rank never announced itself" : !all_healthy ? "a rank cannot join a communicator" : rc != ZWZ_OK ? "rank 0 failed" : "every rank is healthy");
+    };
 
     if (operation == "compress") {
         char record[4096] = "";
@@ -343,7 +394,8 @@ int main(int argc, char* argv[]) {
             if (rc == ZWZ_OK && !record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
             printf("File record saved location: %s\n", record);
             if (trace) fprintf(stderr, "zwz: file list ready at %.3f s\n", since());
-            if (world_size > 1) { rv.payload = std::string(record) + "\t" + nccl_hex; if (!rv.publish_to_all()) fprintf(stderr, "rank 0: not every rank announced itself; going on\n"); }
+            make_id();
+            if (world_size > 1) { rv.payload = std::string(record) + "\t" + nccl_hex; rv.publish(); if (!all_here) fprintf(stderr, "rank 0: not every rank announced itself; going on\n"); }
         } else if (world_size > 1) {   // the reference broadcasts the record path (main.cpp:24-39)
             if (!rv.accept()) { fprintf(stderr, "rank %d: no file list from rank 0\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
             else {
@@ -363,23 +415,45 @@ int main(int argc, char* argv[]) {
             if (world_rank == 0) { FILE* f = fopen(record, "rb"); if (f) { char buf[65536]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) listing.append(buf, k); fclose(f); } }
             if (!nc.broadcast(listing)) { fprintf(stderr, "rank %d: RCCL broadcast of the file list failed\n", world_rank); rc = ZWZ_E_IO; }
             else if (world_rank != 0) {
-                private_list = "/tmp/zwz_list_r" + std::to_string(world_rank) + "_" + rv.nonce + ".txt";
-                if (!write_atomic(private_list, listing)) { fprintf(stderr, "rank %d: cannot write %s\n", world_rank, private_list.c_str()); rc = ZWZ_E_IO; }
+                char tmpl[] = "/tmp/zwz_list_XXXXXX";                         // (created exclusively: nothing in a shared /tmp can stand in its place)
+                const int fd = mkstemp(tmpl);
+                bool ok = fd >= 0;
+                for (size_t off = 0; ok && off < listing.size();) { const ssize_t k = write(fd, listing.data() + off, listing.size() - off); if (k <= 0) ok = false; else off += (size_t)k; }
+                if (fd >= 0) { close(fd); private_list = tmpl; }
+                if (!ok) { fprintf(stderr, "rank %d: cannot write a private copy of the file list under /tmp\n", world_rank); rc = ZWZ_E_IO; }
                 else snprintf(record, sizeof record, "%s", private_list.c_str());
             }
             if (trace) fprintf(stderr, "zwz: rank %d has the list (%zu bytes) over RCCL\n", world_rank, listing.size());
         }
+        // ZWZ_GATHER=1 (with RCCL): ranks other than 0 write their shard into a private directory and hand it to rank 0 over the
+        // communicator; rank 0 writes it to <dst> -- <dst> then only has to exist on rank 0's host.
+        const bool gather = nc.on && getenv("ZWZ_GATHER") && !strcmp(getenv("ZWZ_GATHER"), "1");
+        std::string shard_dir = output_path;
+        if (gather && world_rank != 0) { char tmpl[] = "/tmp/zwz_shard_XXXXXX"; if (mkdtemp(tmpl)) shard_dir = tmpl; else { fprintf(stderr, "rank %d: cannot create a private shard directory\n", world_rank); rc = ZWZ_E_IO; } }
         if (rc == ZWZ_OK) {
             printf("file_record: %s\n", record);
-            if (world_rank < zwz_count_non_empty_lines(record)) rc = zwz_compress_dir(ctx, source_path.c_str(), output_path.c_str(), record, world_rank, world_size);
+            if (world_rank < zwz_count_non_empty_lines(record)) rc = zwz_compress_dir(ctx, source_path.c_str(), shard_dir.c_str(), record, world_rank, world_size);
             else printf("Rank: %d - No file to compress\n", world_rank);
+        }
+        if (gather) {       // every rank of the communicator, whatever its own status (a failed rank contributes an empty shard)
+            const std::string mine_path = shard_dir + "/compressed_" + std::to_string(world_rank) + ".zwz";
+            std::string mine;
+            if (rc == ZWZ_OK && world_rank != 0) (void)read_all(mine_path, mine);
+            std::vector<std::string> blobs;
+            if (!nc.gather_blobs(mine, blobs)) { fprintf(stderr, "rank %d: RCCL gather of the shards failed\n", world_rank); if (rc == ZWZ_OK) rc = ZWZ_E_IO; }
+            else if (world_rank == 0)
+                for (int r = 1; r < world_size; r++)
+                    if (!blobs[(size_t)r].empty() && !write_atomic(output_path + "/compressed_" + std::to_string(r) + ".zwz", blobs[(size_t)r])) { fprintf(stderr, "rank 0: cannot write rank %d's shard\n", r); if (rc == ZWZ_OK) rc = ZWZ_E_IO; }
+            if (trace) fprintf(stderr, "zwz: rank %d: shards gathered over RCCL\n", world_rank);
+            if (world_rank != 0 && shard_dir != output_path) { unlink(mine_path.c_str()); rmdir(shard_dir.c_str()); }
         }
         if (!private_list.empty()) unlink(private_list.c_str());
     } else {
         // The reference decodes on rank 0 only (main.cpp:61-68).  Here every rank takes its share: whole shards round-robin,
         // or record ranges of a shard when there are fewer shards than ranks (zwz_decompress_dir_ranked).
+        if (world_size == 1) make_id();                                      // (ZWZ_COMM=rccl with one rank: a one-rank communicator)
         if (world_size > 1) {
-            if (world_rank == 0) { rv.payload = "\t" + nccl_hex; if (!rv.publish_to_all()) { fprintf(stderr, "rank 0: not every rank announced itself\n"); if (rc == ZWZ_OK) rc = 3; } }
+            if (world_rank == 0) { make_id(); rv.payload = "\t" + nccl_hex; rv.publish(); if (!all_here) { fprintf(stderr, "rank 0: not every rank announced itself\n"); if (rc == ZWZ_OK) rc = 3; } }
             else if (!rv.accept()) { fprintf(stderr, "rank %d: rank 0 never showed up\n", world_rank); if (rc == ZWZ_OK) rc = 3; }
             else { const size_t tab = rv.payload.find('\t'); if (tab != std::string::npos) nccl_hex = rv.payload.substr(tab + 1); }
         }

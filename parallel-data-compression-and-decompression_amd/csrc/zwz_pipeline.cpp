@@ -839,7 +839,7 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         }
     };
 
-    if (nslices) start_fill(0);
+    if (nslices && rc == ZWZ_OK) start_fill(0);
     for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
         pool.wait(fill_group[s & 1]);
         rc = launch_gpu(s);
@@ -869,14 +869,16 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
 // neighbour.  Then every rank writes its range at its offsets; a second exchange is the barrier after which the rank
 // holding a shared file's last record verifies its MD5.  <dst> must be one file system for all ranks (as for the
 // reference, whose ranks share everything).
+// rc_in: what went wrong on this rank before it got here (the shard could not be mapped): it then decodes nothing but still
+// takes part in both exchanges with its failure flag -- its peers are waiting there (a collective has no time-out).
 int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<FileInst>& insts, DecodeSink& sink, int rank, int nranks,
-                       zwz_allgather_u64_fn exchange, void* user) {
+                       zwz_allgather_u64_fn exchange, void* user, int rc_in) {
     std::vector<Job> jobs;
-    for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
+    if (rc_in == ZWZ_OK) for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
     const uint64_t T = jobs.size();
     const uint32_t j0 = (uint32_t)(T * (uint64_t)rank / (uint64_t)nranks), j1 = (uint32_t)(T * (uint64_t)(rank + 1) / (uint64_t)nranks);
     const uint32_t n = j1 - j0;
-    int rc = ZWZ_OK;
+    int rc = rc_in;
     uint8_t* d_big = nullptr; uint32_t* d_lens = nullptr; uint32_t* d_stat = nullptr;
     std::vector<uint32_t> lens(n);
     Slices sl;
@@ -894,10 +896,9 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)n * ZWZ_DEV_STRIDE);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), (size_t)n * sizeof(uint32_t));
-        if (e != hipSuccess) { cleanup(); set_error("record range of %u chunks does not fit device memory: %s", n, hipGetErrorString(e)); return ZWZ_E_NOMEM; }
-        rc = make_slices(c, cap, sl);
-        if (rc) { cleanup(); return rc; }
-        have_slices = true;
+        // (no early return on any of these: the failure travels through the exchanges below)
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("record range of %u chunks does not fit device memory: %s", n, hipGetErrorString(e)); rc = ZWZ_E_NOMEM; }
+        else { rc = make_slices(c, cap, sl); have_slices = rc == ZWZ_OK; }
     }
     Pool::Group fill_group[2], write_group;
     Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group}};
@@ -918,7 +919,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
             });
         }
     };
-    if (nslices) start_fill(0);
+    if (nslices && rc == ZWZ_OK) start_fill(0);
     for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, m = std::min(n, g0 + cap) - g0;
@@ -1050,12 +1051,17 @@ int decompress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, in
         Mapped blob;
         bool opened = false;
         rc = map_shard(shards[j], blob, opened);
+        if (rc && split) {      // the other ranks are on their way into this shard's exchanges: join them, failure flag up
+            std::vector<FileInst> none;
+            DecodeSink sink{dst_dir, none, mismatches, log_mutex};
+            (void)decode_shard_split(c, pool, blob, none, sink, rank, nranks, exchange, user, rc);
+        }
         if (rc) break;
         if (!opened && !split) continue;
         std::vector<FileInst> insts;
         if (!parse_shard(blob, insts)) { damaged = true; if (rank == 0 || !split) fprintf(stderr, "Malformed shard (damaged from some record on): %s\n", shards[j].c_str()); }
         DecodeSink sink{dst_dir, insts, mismatches, log_mutex};
-        rc = split ? decode_shard_split(c, pool, blob, insts, sink, rank, nranks, exchange, user) : decode_whole_shard(c, pool, blob, insts, sink);
+        rc = split ? decode_shard_split(c, pool, blob, insts, sink, rank, nranks, exchange, user, ZWZ_OK) : decode_whole_shard(c, pool, blob, insts, sink);
         if (rc) break;
     }
     if (md5_mismatches) *md5_mismatches = mismatches.load();

@@ -215,3 +215,40 @@ def test_multirank_decompress_matches_reference_tree(tmp_path, golden_dir, world
         assert info["rc"] == 0 and info["calls"] == [[r, world, True]]
         assert info["big"] == [v for k in range(world) for v in (k, (1 << 64) - 1 - k)]
         assert ("Time Taken:" in info["stdout"]) == (r == 0)
+
+
+def _failing_worker(rank, world, init_file, src, dst, record, gather, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_binding
+    cli = importlib.import_module(PKG + ".cli")
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    oracle = oracle_binding.load()
+
+    def compress_fn(in_dir, out_dir, rec, r, n):
+        if r == 1:
+            raise RuntimeError("rank 1's device fell over")
+        assert oracle.compress_shard(in_dir, out_dir, rec, r, n) == 0
+
+    os.environ["ZWZ_FILE_RECORD"] = record if rank == 0 else "/nonexistent"
+    out = io.StringIO()
+    rc = cli.run("compress", src, dst, compress_fn=compress_fn, decompress_fn=lambda a, b, r, n, ag: 0, sort_fn=lambda p: record,
+                 count_fn=lambda path: sum(1 for line in open(path).read().split("\n") if line.strip()), gather=gather, out=out)
+    with open(os.path.join(result_dir, "r%d.json" % rank), "w") as f:
+        json.dump({"rc": rc}, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_a_failed_rank_still_joins_the_collectives(tmp_path, golden_dir, gather):
+    """A rank whose codec call raises must not leave its peers inside the shard gather or the final barrier (they have no
+    time-out there): it takes part with its failure flag, and every rank returns non-zero."""
+    import torch.multiprocessing as mp
+    src, dst, res = tmp_path / "src", tmp_path / "dst", tmp_path / "res"
+    res.mkdir()
+    _write_tree(str(src))
+    rec = tmp_path / "list.txt"
+    rec.write_text(json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["2"]["sorted_list"])
+    mp.spawn(_failing_worker, args=(2, str(tmp_path / "rdzv"), str(src), str(dst), str(rec), gather, str(res)), nprocs=2, join=True)
+    assert [json.load(open(res / ("r%d.json" % r)))["rc"] for r in range(2)] == [2, 2]
