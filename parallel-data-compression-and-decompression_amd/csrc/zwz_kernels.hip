@@ -145,7 +145,8 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
         const uint32_t Lr = (q.L + 15u) & ~15u;                              // the slot is readable this far
         const uint8_t* pa = q.data + (o + 4u <= Lr ? o : 0u);
         const uint8_t* pt = q.data + (o + 8u <= Lr ? o + 4u : 0u);
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
+        // (the trailing comments put the operands' physical registers into the ISA text: tests/test_generated.py reads them there)
+        asm volatile("global_load_dword %0, %2, off ; zwz-feeder load\n\tglobal_load_dword %1, %3, off ; zwz-feeder load" : "+v"(S.c), "+v"(S.t) : "v"(pa), "v"(pt) : "memory");
     };
     auto pad_stores = [&](uint32_t cnt) {          // stores with no effect, where a trip has no links to write out (the counted wait below wants every trip's)
         for (uint32_t i = 0; i < cnt; i++) asm volatile("global_store_short %0, %1, off" :: "v"(lk_spare), "v"(0u) : "memory");
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
     uint32_t* hbuf32 = reinterpret_cast<uint32_t*>(hbuf);                       // 32-bit entries: bucket address in, link out
     auto hash_block = [&](const Cursor& q, auto slot) { // bucket addresses of positions [2048 k + fpos, + 4) from the loaded input
         InSet& S = in_ring[decltype(slot)::value];
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.c), "+v"(S.t) : "n"(kWait) : "memory");
+        asm volatile("s_waitcnt vmcnt(%2) ; zwz-feeder covers %0 %1" : "+v"(S.c), "+v"(S.t) : "n"(kWait) : "memory");
         const uint32_t in_w[2] = {S.c, S.t};
         const uint32_t o = q.k * kLinksBlock + fpos, L = q.L;
         const uint32_t n_ok = L >= o + kMinMatch ? min(kPer, L - o - (kMinMatch - 1u)) : 0u;   // this lane's positions with a trigram (none past the last chunk)
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 #undef ZWZ_LINKS_TRIP
         // The last requests (for blocks past the stream's end) are still in flight, into registers the compiler considers dead from
         // here on: they must land before anything else is computed in them (the flush below built a store's data, or address, in one).
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_ring[0].c), "+v"(in_ring[0].t), "+v"(in_ring[1].c), "+v"(in_ring[1].t), "+v"(in_ring[2].c), "+v"(in_ring[2].t) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0) ; zwz-feeder drains %0 %1 %2 %3 %4 %5" : "+v"(in_ring[0].c), "+v"(in_ring[0].t), "+v"(in_ring[1].c), "+v"(in_ring[1].t), "+v"(in_ring[2].c), "+v"(in_ring[2].t) :: "memory");
         if (!first_trip && fl.c < n) {              // the stream's last block, if its length is a multiple of three (fl is one behind)
             flush_block(fl);
             chunk_done(fl);

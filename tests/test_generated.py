@@ -24,3 +24,98 @@ def test_links_block_waits_never_exceed_the_queue():
         gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_links_block.py"), str(ahead), str(behind)], capture_output=True, text=True, check=True)
         waits = [int(l.split("lgkmcnt(")[1].split(")")[0]) for l in gen.stdout.splitlines() if "lgkmcnt(" in l]
         assert waits and max(waits) <= 15
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lz_links' feeders keep input loads in flight, across three hand-overs, in registers that only inline asm writes: the compiler
+# takes an asm output for ready the moment the statement is behind it, so nothing but its goodwill stops it from copying,
+# spilling or reusing such a register while the load is still landing (round 2: a GPU memory fault).
+# The kernel's asm statements therefore print their operands' physical registers into the ISA text (comments "zwz-feeder
+# load / covers / drains"), and this test walks the gfx950 ISA of lz_links in layout order with the set of registers in
+# flight: a load adds its destination, the counted wait that covers a set removes it, the drain behind the loop empties it --
+# and NO other instruction may name a register while it is in the set.
+import re
+import shutil
+
+import pytest
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _feeder_violations(asm_text):
+    body = asm_text.split("lz_links_kernel", 1)[1]
+    body = body[:body.index("s_endpgm")]
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+    def regs_of(text):
+        out = set()
+        for m in reg.finditer(text):
+            if m.group(1) is not None:
+                out.add(int(m.group(1)))
+            else:
+                out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        return out
+
+    in_flight, sets, problems, n_loads, drained = set(), set(), [], 0, False
+    for no, line in enumerate(body.splitlines()):
+        code, _, comment = line.partition(";")
+        code = code.strip()
+        if "zwz-feeder load" in comment:
+            dst = regs_of(code.split(",")[0])
+            assert len(dst) == 1
+            if drained:
+                problems.append((no, "a load behind the drain", line.strip()))
+            in_flight |= dst
+            n_loads += 1
+            continue
+        if "zwz-feeder covers" in comment:
+            pair = frozenset(regs_of(comment))
+            assert len(pair) == 2
+            if not pair <= in_flight:
+                problems.append((no, "a wait for registers that are not in flight", line.strip()))
+            sets.add(pair)
+            in_flight -= pair
+            continue
+        if "zwz-feeder drains" in comment:
+            if regs_of(comment) != set().union(*sets) or "vmcnt(0)" not in code:
+                problems.append((no, "the drain does not name the three sets", line.strip()))
+            in_flight.clear()
+            drained = True
+            continue
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        hit = regs_of(code) & in_flight
+        if hit:
+            problems.append((no, "v%d is named while a load into it is in flight" % min(hit), line.strip()))
+    if in_flight:
+        problems.append((-1, "registers still in flight at the kernel's end: no drain", sorted(in_flight)))
+    return problems, sets, n_loads, drained
+
+
+def _lz_links_isa(source_text, tmp_path):
+    src = tmp_path / "zwz_kernels.hip"
+    csrc = os.path.join(ROOT, "parallel-data-compression-and-decompression_amd", "csrc")
+    src.write_text(source_text)
+    out = tmp_path / "k.s"
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I", csrc, "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(out)], check=True, capture_output=True)
+    return out.read_text()
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (cross-compiles gfx950 without a GPU)")
+def test_feeder_registers_are_untouched_while_their_loads_are_in_flight(tmp_path):
+    src = open(os.path.join(ROOT, "parallel-data-compression-and-decompression_amd", "csrc", "zwz_kernels.hip")).read()
+    src = src.replace('#include "../../include/zwz.h"', '#include "zwz.h"')
+    problems, sets, n_loads, drained = _feeder_violations(_lz_links_isa(src, tmp_path))
+    assert not problems, problems[:5]
+    assert len(sets) == 3 and len(set().union(*sets)) == 6 and n_loads >= 8 and drained      # three sets of two, asked for in the prologue and the loop
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (cross-compiles gfx950 without a GPU)")
+def test_feeder_check_catches_the_round_2_fault(tmp_path):
+    """The same source without the drain behind the feeders' loop -- the state in which the kernel faulted -- must not pass."""
+    src = open(os.path.join(ROOT, "parallel-data-compression-and-decompression_amd", "csrc", "zwz_kernels.hip")).read()
+    drain = [l for l in src.splitlines() if "zwz-feeder drains" in l]
+    assert len(drain) == 1
+    problems, _, _, drained = _feeder_violations(_lz_links_isa(src.replace(drain[0], ""), tmp_path))
+    assert problems and not drained
