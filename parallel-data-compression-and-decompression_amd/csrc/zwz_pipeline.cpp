@@ -445,6 +445,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     // -- a single buffered writer copied every payload twice and was the whole pipeline's pace (1.9 GB/s).
     uint32_t truncated = 0;
     uint64_t out_pos = 0;                        // shard bytes laid out so far
+    const uint32_t consumers = [] { const char* v = getenv("ZWZ_CONSUMERS"); const long k = v ? atol(v) : 1; return (uint32_t)(k < 1 ? 1 : k > 64 ? 64 : k); }();
     std::atomic<int> write_error{0};
     struct Rec { uint64_t off; uint32_t slot; int32_t path_len, seq, payload; uint8_t last; const std::string* rel; const char* md5; };
     std::vector<Rec> recs;
@@ -454,10 +455,30 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
         recs.clear(); recs.reserve(g1 - g0);
         hexes.resize((size_t)cap * 32);          // (sl.n_md5[b] already counts the slice being read into this buffer pair)
-        uint32_t fi = file_of(g0);
-        for (uint32_t g = g0; g < g1; g++) {
-            while (g >= files[fi].first_chunk + files[fi].nchunks) fi++;
-            const File& f = files[fi];
+        // SURVEY.md section 8 f4, opt-in and never default: ZWZ_CONSUMERS=k writes a slice's records the way k of the reference's
+        // consumers (process.hpp:13 NUM_CONSUMERS, shipped as 1) might finish them -- every run of k consecutive chunks of a file
+        // back to front -- except a file's last chunk, which stays behind all its others: the reference's reader finalises a file
+        // only when its last record arrives in turn (decompression.cpp:132).  Readers put the chunks back by sequence_id.
+        std::vector<uint32_t> order(g1 - g0), file_idx(g1 - g0);
+        {
+            uint32_t fi = file_of(g0);
+            for (uint32_t g = g0; g < g1; g++) {
+                while (g >= files[fi].first_chunk + files[fi].nchunks) fi++;
+                order[g - g0] = g; file_idx[g - g0] = fi;
+            }
+            if (consumers > 1)
+                for (uint32_t i = 0; i < g1 - g0;) {
+                    const uint32_t fi2 = file_idx[i];
+                    uint32_t j = i;
+                    while (j < g1 - g0 && file_idx[j] == fi2 && order[j] + 1u != files[fi2].first_chunk + files[fi2].nchunks && j - i < consumers) j++;
+                    if (j == i) { i++; continue; }                          // a file's last chunk: where it is
+                    std::reverse(order.begin() + i, order.begin() + j);
+                    i = j;
+                }
+        }
+        for (uint32_t e = 0; e < g1 - g0; e++) {
+            const uint32_t g = order[e];
+            const File& f = files[file_idx[g - g0]];
             Rec r;
             r.slot = g - g0; r.seq = (int32_t)(g - f.first_chunk); r.last = r.seq + 1 == (int32_t)f.nchunks;
             r.path_len = (int32_t)f.rel.size(); r.payload = (int32_t)sl.h_olen[b][r.slot]; r.rel = &f.rel; r.md5 = nullptr;

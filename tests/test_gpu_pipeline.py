@@ -345,3 +345,44 @@ def test_cli_rccl_collectives_single_rank(golden_dir, tmp_path):
     for rel, want in run["decoded"].items():
         b = open(back / rel, "rb").read()
         assert {"size": len(b), "sha256": sha(b)} == want, rel
+
+
+def test_parallel_consumers_write_records_out_of_order(zwz, tmp_path, monkeypatch):
+    """SURVEY.md section 8 f4, opt-in: ZWZ_CONSUMERS=k emits a file's chunks the way k consumers might finish them (runs of k back to
+    front, the file's last chunk behind all its others).  Same records as the default shard, in another order; this decoder
+    and the reference's own (decompression.cpp:119-153 puts chunks back by sequence_id) restore the tree with matching MD5s."""
+    import zwz_records
+    src = tmp_path / "data" / "src"
+    src.mkdir(parents=True)
+    files = {"a.txt": corpus.text_like(81, 400000), "b.bin": corpus.low_entropy(82, 3 * 65535), "c.txt": corpus.text_like(83, 70000), "d.bin": corpus.skewed(84, 1000), "e.bin": b""}
+    for n, d in files.items():
+        (src / n).write_bytes(d)
+    rec = tmp_path / "list.txt"
+    rec.write_text("".join(n + "\n" for n in files))
+    plain, mixed = tmp_path / "plain", tmp_path / "mixed"
+    plain.mkdir(); mixed.mkdir()
+    c = zwz.Codec(0, 256)
+    try:
+        c.do_compression(str(src), str(plain), str(rec), 0, 1)
+        monkeypatch.setenv("ZWZ_CONSUMERS", "3")
+        c.do_compression(str(src), str(mixed), str(rec), 0, 1)
+        monkeypatch.delenv("ZWZ_CONSUMERS")
+        r0 = zwz_records.parse(open(plain / "compressed_0.zwz", "rb").read())
+        r1 = zwz_records.parse(open(mixed / "compressed_0.zwz", "rb").read())
+        assert sorted(r0) == sorted(r1) and r0 != r1                           # the same records, another order
+        seqs = [r[1] for r in r1 if r[0] == b"a.txt"]
+        assert seqs[:6] == [2, 1, 0, 5, 4, 3] and seqs[-1] == max(seqs)        # runs of three back to front; the last chunk last
+        back = tmp_path / "back"
+        back.mkdir()
+        assert c.do_decompression(str(mixed), str(back)) == 0
+        for n, d in files.items():
+            assert open(back / n, "rb").read() == d, n
+    finally:
+        c.close()
+    ref = os.path.join(ROOT, "oracle", "_ref", "main")
+    if os.path.exists(ref):
+        b3 = tmp_path / "b3"
+        r = subprocess.run([ref, "decompress", str(mixed), str(b3)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "MD5 mismatch" not in r.stderr and r.stdout.count("MD5 match") == len(files)
+        for n, d in files.items():
+            assert open(b3 / n, "rb").read() == d, n
