@@ -735,8 +735,17 @@ void pwrite_chunks(int fd, uint64_t off, std::vector<struct iovec>& iov) {
 int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<FileInst>& insts, DecodeSink& sink) {
     std::vector<Job> jobs;
     for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
-    struct OutState { FILE* f = nullptr; int fd = -1; uint64_t written = 0; Md5 md5; uint32_t remaining = 0; bool failed = false; bool deferred = false; };
+    struct OutState { FILE* f = nullptr; int fd = -1; uint64_t written = 0; Md5 md5; uint32_t remaining = 0; bool failed = false; bool deferred = false;
+                      int32_t gpu_md5 = -1; };      // index into its slice's GPU digest list, or -1: hashed by the task that writes it
     std::vector<OutState> outs(insts.size());
+    // SURVEY.md section 8 f1, second call site (decompression.cpp:136): a file decoded whole within one slice (and no longer than the
+    // 64 chunks a lane is asked to hash on the compress side) sits in consecutive output slots on the device -- its MD5 is taken
+    // there by md5_files_kernel, one lane per file, before the bytes come back; the writing task then only writes.  Files that
+    // span slices are hashed from disk as before; ZWZ_HOST_MD5=1 keeps every digest on the host.
+    const bool gpu_md5 = getenv("ZWZ_HOST_MD5") == nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_gpu_wait = 0, t_write_wait = 0;
     for (uint32_t i = 0; i < insts.size(); i++) outs[i].remaining = (uint32_t)insts[i].order.size();
     const uint32_t T = (uint32_t)jobs.size();
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
@@ -764,16 +773,30 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         outs[inst].f = fopen(file_path.c_str(), "wb");
         if (!outs[inst].f) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); outs[inst].failed = true; }
     };
-    auto finish_out = [&](uint32_t inst) {
+    auto finish_out = [&](uint32_t inst, const uint8_t* digest /* 16 bytes from the GPU, or null */) {
         OutState& o = outs[inst];
         if (o.f) { fclose(o.f); o.f = nullptr; }
         char hex[33];
-        o.md5.hex(hex);
+        if (digest) { static const char* dig = "0123456789abcdef"; for (int i = 0; i < 16; i++) { hex[2 * i] = dig[digest[i] >> 4]; hex[2 * i + 1] = dig[digest[i] & 15]; } hex[32] = 0; }
+        else o.md5.hex(hex);
         sink.verdict(inst, hex);
     };
     auto start_fill = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
+        sl.n_md5[b] = 0;
+        if (gpu_md5)
+            for (uint32_t g = g0; g < g1;) {
+                uint32_t e = g;
+                while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
+                OutState& o = outs[jobs[g].inst];
+                if (!o.deferred && e - g <= 64u && e - g == (uint32_t)insts[jobs[g].inst].order.size()) {
+                    o.gpu_md5 = (int32_t)sl.n_md5[b];
+                    sl.h_files[b][2 * sl.n_md5[b]] = g - g0; sl.h_files[b][2 * sl.n_md5[b] + 1] = e - g;
+                    sl.n_md5[b]++;
+                }
+                g = e;
+            }
         for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
             const uint32_t u1 = std::min(g1, u0 + 256);
             pool.submit(fill_group[b], [&, b, g0, u0, u1] {
@@ -795,6 +818,12 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         int r = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b], sl.d_st[b]);
         if (r) return r;
+        if (sl.n_md5[b]) {      // (output slot k sits at k * 65536, which is what d_off holds for the input slots)
+            HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, c->stream));
+            r = zwz_md5_files_dev(c, sl.d_out[b], sl.d_off[b], sl.d_olen[b], sl.d_files[b], sl.n_md5[b], sl.d_dig[b]);
+            if (r) return r;
+            HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(sl.done[b], c->stream));
@@ -821,10 +850,10 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
                         const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
                         const uint32_t n = sl.h_olen[b][k - g0];
                         if (o.f) fwrite(src, 1, n, o.f);
-                        o.md5.update(src, n);
+                        if (o.gpu_md5 < 0) o.md5.update(src, n);
                     }
                     o.remaining -= a1 - a0;
-                    if (o.remaining == 0) finish_out(inst);
+                    if (o.remaining == 0) finish_out(inst, o.gpu_md5 >= 0 ? sl.h_dig[b] + (size_t)o.gpu_md5 * 16 : nullptr);
                 });
             } else {
                 if (os.fd < 0 && !os.failed) {
@@ -852,7 +881,7 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
             }
             g = e;
         }
-        pool.wait(write_group);              // the next slice of a file must follow this one
+        { const double t0 = since(); pool.wait(write_group); t_write_wait += since() - t0; }   // the next slice of a file must follow this one
         for (uint32_t inst : finished) {
             OutState& o = outs[inst];
             if (o.fd >= 0) { close(o.fd); o.fd = -1; }
@@ -865,20 +894,25 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         pool.wait(fill_group[s & 1]);
         rc = launch_gpu(s);
         if (rc) break;
-        if (s >= 1) { hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
+        if (s >= 1) { const double t0 = since(); hipError_t e = hipEventSynchronize(sl.done[(s - 1) & 1]); t_gpu_wait += since() - t0; if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; } }
         if (s + 1 < nslices) start_fill(s + 1);
         if (s >= 1) write_slice(s - 1);
     }
     if (rc == ZWZ_OK && nslices) {
+        const double t0 = since();
         hipError_t e = hipEventSynchronize(sl.done[(nslices - 1) & 1]);
+        t_gpu_wait += since() - t0;
         if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else write_slice(nslices - 1);
     }
+    const double t_slices = since();
     pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(md5_group);
+    if (verbose()) fprintf(stderr, "zwz: decode: %u records of %zu files in %u slices done at %.3f s (waited %.3f s for the GPU, %.3f s for the writers); "
+                                   "spanning files hashed by %.3f s\n", T, insts.size(), nslices, t_slices, t_gpu_wait, t_write_wait, since());
     (void)hipStreamSynchronize(c->stream);
     free_slices(sl);
     // instances that never received a decodable record still get created (the reference opens on the first record of a path)
     for (uint32_t i = 0; i < insts.size(); i++)
-        if (insts[i].order.empty()) { open_out(i); finish_out(i); }
+        if (insts[i].order.empty()) { open_out(i); finish_out(i, nullptr); }
     return rc;
 }
 
