@@ -192,6 +192,7 @@ void zwz_ctx_destroy(zwz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->workspace) (void)hipFree(c->workspace);
+    if (c->inf_order) (void)hipFree(c->inf_order);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -269,7 +270,13 @@ int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
     if (!c || (n && (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_len || !d_status))) return ZWZ_E_INVALID;
     if (out_stride < ZWZ_CHUNK_SIZE || ((uintptr_t)d_in & 15u)) return ZWZ_E_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status};
+    if (n > c->inf_order_cap) {     // scratch for the launch order (longest payloads first)
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->inf_order) { (void)hipFree(c->inf_order); c->inf_order = nullptr; c->inf_order_cap = 0; }
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->inf_order), (size_t)n * sizeof(uint4)));
+        c->inf_order_cap = n;
+    }
+    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status, c->inf_order};
     if (c->profiling) HIPCHK(hipEventRecord(c->ev_inf[0], c->stream));
     HIPCHK(launch_inflate(a, c->stream));
     if (c->profiling) {

@@ -11,6 +11,8 @@ struct zwz_ctx {
     hipStream_t stream = nullptr;
     void* workspace = nullptr;
     uint32_t ws_chunks = 0;          // chunks the workspace is currently sized for
+    uint4* inf_order = nullptr;      // inflate's launch order ((offset, length, chunk) by payload length), grown to the largest batch seen
+    uint32_t inf_order_cap = 0;
     // staging for the host-buffer entry points and the directory pipeline
     void* d_stage = nullptr;
     void* h_stage = nullptr;

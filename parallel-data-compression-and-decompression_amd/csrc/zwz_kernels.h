@@ -90,6 +90,7 @@ struct DeflateArgs {
 struct InflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;
     uint8_t* out; uint64_t out_stride; uint32_t* out_len; uint32_t* status;
+    uint4* order;              // n entries of scratch (the launch fills it: (offset, length, chunk) by payload length, longest first), or null: as they come
 };
 
 constexpr size_t kTicketBytes = 256;

@@ -1867,15 +1867,20 @@ struct InflateWaveMem {
 __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                   const uint32_t* __restrict__ in_len, uint32_t n,
                                                                   uint8_t* __restrict__ out, uint64_t out_stride,
-                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status) {
+                                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
+                                                                  const uint4* __restrict__ order /* (offset, length, chunk) longest payloads first, or null */) {
     __shared__ InflateWaveMem s_mem[kInflateThreads / 64];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = blockIdx.x * (kInflateThreads / 64) + wave;
-    if (chunk >= n) return;
+    const uint32_t slot = blockIdx.x * (kInflateThreads / 64) + wave;
+    if (slot >= n) return;
+    // (the order's entry carries the chunk's offset and length along: read through a chunk number they were a second, dependent
+    // round trip at the head of every wave -- a fifth of a stored chunk's whole time)
+    const uint4 oe = order ? order[slot] : make_uint4(0, 0, 0, slot);
+    const uint32_t chunk = oe.w;
     InflateWaveMem& m = s_mem[wave];
-    const uint8_t* src = in + in_off[chunk];          // 16-byte aligned (API contract)
+    const uint8_t* src = in + (order ? ((uint64_t)oe.y << 32 | oe.x) : in_off[chunk]);   // 16-byte aligned (API contract)
     uint8_t* dst = out + (size_t)chunk * out_stride;
-    const uint32_t nin = in_len[chunk];
+    const uint32_t nin = order ? oe.z : in_len[chunk];
     const uint32_t nin16 = (nin + 15u) & ~15u;         // readable extent (API contract)
 
     uint32_t fill_end = 0;                             // ring holds payload bytes [fill_end - 2048, fill_end)
@@ -2437,11 +2442,60 @@ hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uin
     return hipGetLastError();
 }
 
+// A chunk is one wave's work from start to end, and a full-size chunk takes a lone wave milliseconds: in a batch of mixed sizes the
+// long ones must start first or they are the batch's tail (370 000 image-like files: the few 64 KB chunks among the 7 KB ones).
+// Counting sort of the chunk numbers by payload length (256-byte classes), longest first; one workgroup, ~20 us per 50 000.
+__global__ __launch_bounds__(1024) void inflate_order_kernel(const uint64_t* __restrict__ in_off, const uint32_t* __restrict__ in_len, uint32_t n, uint4* __restrict__ order) {
+    __shared__ uint32_t s_bin[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256u) s_bin[tid] = 0;
+    __syncthreads();
+    auto cls = [](uint32_t len) { const uint32_t c = len >> 8; return 255u - (c < 255u ? c : 255u); };      // longest first
+    // (lanes of a wave that share a class add to its counter as one: a batch of equal-sized chunks would otherwise be
+    // 50 000 additions to the same LDS word, one after the other)
+    auto grouped_add = [&](uint32_t c, bool live) -> uint32_t {           // -> the lane's slot; wave-uniform control flow
+        uint32_t slot = 0;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(live);
+        while (todo) {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(todo));
+            const uint64_t m = __builtin_amdgcn_ballot_w64(live && c == c0);
+            uint32_t base = 0;
+            if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_bin[c0], (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+            if (live && c == c0) slot = base + rank_in(m);
+            todo &= ~m;
+        }
+        return slot;
+    };
+    for (uint32_t i = tid; i - tid < n; i += 1024u) (void)grouped_add(i < n ? cls(in_len[i]) : 0u, i < n);
+    __syncthreads();
+    // A batch of one or two sizes (incompressible files: full chunks and 4-byte tails) keeps the order it came in: there is no
+    // tail to shorten, and its copies, which run at HBM speed, lost a fifth of it when neighbouring slots were no longer
+    // neighbouring waves.
+    const bool keep = __syncthreads_count(tid < 256u && s_bin[tid] != 0u) <= 2;
+    if (keep) {
+        for (uint32_t i = tid; i < n; i += 1024u) { const uint64_t off = in_off[i]; order[i] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), in_len[i], i); }
+        return;
+    }
+    if (tid < 64u) {                                                       // exclusive scan of the 256 counts by one wave, four a lane
+        const uint32_t a = s_bin[4 * tid], b = s_bin[4 * tid + 1], c = s_bin[4 * tid + 2], d = s_bin[4 * tid + 3];
+        const uint32_t own = a + b + c + d, ex = wave_scan_incl(own) - own;
+        s_bin[4 * tid] = ex; s_bin[4 * tid + 1] = ex + a; s_bin[4 * tid + 2] = ex + a + b; s_bin[4 * tid + 3] = ex + a + b + c;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i - tid < n; i += 1024u) {
+        const uint32_t len = i < n ? in_len[i] : 0u;
+        const uint32_t slot = grouped_add(cls(len), i < n);
+        if (i < n) { const uint64_t off = in_off[i]; order[slot] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), len, i); }
+    }
+}
+
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const uint32_t per = kInflateThreads / 64;
+    if (a.order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(1024), 0, s, a.in_off, a.in_len, a.n, a.order);
     hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
-                       a.out_stride, a.out_len, a.status);
+                       a.out_stride, a.out_len, a.status, (const uint4*)a.order);
     return hipGetLastError();
 }
 
