@@ -197,15 +197,23 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
                 for (uint32_t j = 0; j < 8; j++) h8[j] = hb[(t * 8u + j) * 64u + lane];
             };
             if (full) ask(0u, hv);
+            uint32_t hp[8], op[8];                                              // the previous trip's hashes and what its adds returned
             for (uint32_t t = 0; t < full; t++) {
                 uint32_t hn[8], old[8];
                 if (t + 1u < full) ask(t + 1u, hn);
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) old[j] = atomicAdd(&tab[hv[j] >> 1], 1u << ((hv[j] & 1u) << 4));
+                // (the previous trip's results are written out while this trip's adds are on their way through the LDS)
+                if (t) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) out[(t * 8u + j) * 64u + lane] = (uint16_t)(old[j] >> ((hv[j] & 1u) << 4));
+                    for (uint32_t j = 0; j < 8; j++) out[((t - 1u) * 8u + j) * 64u + lane] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                }
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) hv[j] = hn[j];
+                for (uint32_t j = 0; j < 8; j++) { hp[j] = hv[j]; op[j] = old[j]; hv[j] = hn[j]; }
+            }
+            if (full) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) out[((full - 1u) * 8u + j) * 64u + lane] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
             }
             for (uint32_t p = full * 512u + lane; p - lane < n; p += 64u) {     // the ragged end, a step at a time
                 if (p < n) {
