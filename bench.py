@@ -389,7 +389,12 @@ def run_workload(args, torch, dist, codec, dev, world, rank, name):
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
         if os.path.exists(tpath) and name in ("random", "text") and (args.files or 10000) == 10000 and args.file_bytes == 262144:
             # PMC passes of this same workload, collected separately (tools/prof_gpu.sh); null if not measured
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            # (a stage of the profile may be several kernels: stage lz_links = marks, links and the sort; stage lz_match = both searches)
+            stage_kernels = {"lz_links": ["lz_dense_list", "lz_lists", "lz_links", "lz_sort", "lz_place"], "lz_match": ["lz_match", "lz_match_band"],
+                             "plan": ["plan_probe", "plan_cost", "plan"], "encode": ["encode_stored", "encode"], "inflate": ["inflate_order", "inflate"]}
+            per_kernel = json.load(open(tpath))
+            got = [per_kernel[k]["hbm_bytes_per_launch"] for k in stage_kernels.get(dom, [dom]) if k in per_kernel]
+            traffic = sum(got) if got else None
         comp_s, dec_s = c1 - c0, c2 - c1
         res = {
             "value": round(raw_all * args.steps / elapsed / 1e9, 3), "unit": "GB/s",

@@ -96,9 +96,11 @@ int zwz_inflate_batch(zwz_ctx *ctx, const uint8_t *in, const uint64_t *in_off, c
                       uint8_t *out, uint32_t *out_len, uint32_t *status);
 
 /* ---- stage timing (HIP events on the context's stream) -------------------------------------
- * With profiling on, every deflate slice records events around its 6 kernels; the accumulated
- * milliseconds since the last reset are returned in ms[0..6) in pipeline order
- * (links, match, parse, blockify, plan, encode), ms[6] = inflate kernel. */
+ * With profiling on, every deflate slice records events around its 6 stages; the accumulated
+ * milliseconds since the last reset are returned in ms[0..6) in pipeline order -- links (marks of the
+ * chain-heavy chunks, chain links of the others, the sorted arrays: lz_dense_list, lz_lists, lz_links,
+ * lz_sort, lz_place), match (lz_match, lz_match_band), parse, blockify, plan (three kernels), encode
+ * (two kernels) --, ms[6] = inflate (its launch order + the kernel). */
 #define ZWZ_NUM_STAGES 7
 int zwz_ctx_set_profiling(zwz_ctx *ctx, int on);
 int zwz_ctx_stage_ms(zwz_ctx *ctx, float *ms, int reset);

@@ -2,21 +2,23 @@
 // compression.cpp:119-134 and decompression.cpp:16-36, rebuilt as a batch pipeline over HBM).
 //
 // Compress, per batch of chunks (stage -> intermediate in HBM -> next stage):
-//   lz_links    9 waves / chunk       15-bit hash + newest-first chain links (zlib's head/prev): eight feeder waves
-//                                     hash and stream, an inserter wave walks the LDS head table, one exchange a step
-//   lz_match    one WG / chunk        per-position best-of-32 / best-of-128 match records; the 32 KiB history
+//   lz_dense_list / lz_lists         (zwz_band.hip) which chunks are chain-heavy: those go lz_sort -> lz_place -> lz_match_band
+//   lz_links    persistent, 1 WG / CU 15-bit hash + newest-first chain links (zlib's head/prev) of the other chunks: eight feeder
+//                                     waves hash and stream, an inserter wave walks the LDS head table, one exchange a step
+//   lz_match    one WG / chunk        per-position best-of-32 / best-of-128 match records of those chunks; the 32 KiB history
 //                                     window (bytes + links) lives in LDS and slides tile by tile
 //   lz_parse    one wave / chunk      lazy-evaluation walk over the records, block-parallel -> symbol bit masks
 //   blockify    one WG / chunk        symbol ranks (popcount prefix), 16383-symbol block cuts,
 //                                     per-block histograms (LDS atomics)
 //   plan_probe / plan_cost / plan     stored / static settled by an optimal-Huffman-cost lower bound (wave per
 //                                     block sorts, lane per block merges); the rest get zlib-exact trees
-//   encode      one WG / chunk        code lengths -> prefix scan -> bit offsets -> LDS bit packing; stored
-//                                     chunks copied straight through; Adler-32, 65535-byte truncation
+//   encode_stored / encode            all-stored chunks copied straight through (one WG / chunk); the rest, persistent, two WGs / CU:
+//                                     code lengths -> prefix scan -> bit offsets -> LDS bit packing; Adler-32, 65535-byte truncation
 // Decompress:
-//   inflate     one wave / chunk      window-parallel Huffman decode, byte-parallel copies
+//   inflate_order / inflate           chunks by payload length, longest first; one wave / chunk: window-parallel Huffman decode,
+//                                     byte-parallel copies
 // Integrity:
-//   md5_files   one lane / file       RFC 1321 over a file's chunk slots
+//   md5_files   one lane / file       RFC 1321 over a file's chunk slots (input slots on compress, output slots on decompress)
 //
 // All stages are integer/byte work bounded by LDS latency and HBM traffic; no MFMA.
 #include <hip/hip_runtime.h>
@@ -2326,17 +2328,19 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     // search (zwz_band.hip).  The rest: chain links, then lz_match's screening pass over them.  ZWZ_MATCH=walk sends every chunk
     // through links + lz_match (its sorted walk included), =band every chunk through the band.
     const uint32_t which = [] { const char* e = getenv("ZWZ_MATCH"); return e && !strcmp(e, "walk") ? 1u : e && !strcmp(e, "band") ? 2u : 0u; }();   // (read per launch: tests flip it)
+    // (stage 0 of the profile = everything that prepares the search: marks and lists, chain links of the sparse chunks, the sorted
+    // arrays of the chain-heavy ones; stage 1 = the searches themselves: lz_match, lz_match_band)
     if (which == 1u) ZWZ_TRY(launch_links(a, s, false));
     else {
         ZWZ_TRY(launch_dense_list(a, s, which));
         ZWZ_TRY(launch_links(a, s, true));
+        ZWZ_TRY(launch_sort(a, s));
+        ZWZ_TRY(launch_place(a, s));
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u);
     if (which != 1u) {
-        ZWZ_TRY(launch_sort(a, s));
-        ZWZ_TRY(launch_place(a, s));
         ZWZ_TRY(launch_match_band(a, s));
         if (getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads
             uint32_t h[64];

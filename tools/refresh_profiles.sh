@@ -2,7 +2,7 @@
 # GPU-box helper: the evidence behind DESIGN.md's tables -- rocprofv3 kernel stats + PMC passes for both headline
 # workloads at full size, then the default bench line (both workloads + CPU baseline).  Results land in gpurun_out/;
 # the summaries are copied into profiles/ under the round's tag.   usage: tools/refresh_profiles.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 $R/tools/prof_gpu.sh random 10000 $TAG > $R/gpurun_out/prof_${TAG}_random.log 2>&1 && \
 timeout -k 10 900 $R/tools/prof_gpu.sh text 10000 $TAG > $R/gpurun_out/prof_${TAG}_text.log 2>&1 && \
