@@ -743,6 +743,19 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     // there by md5_files_kernel, one lane per file, before the bytes come back; the writing task then only writes.  Files that
     // span slices are hashed from disk as before; ZWZ_HOST_MD5=1 keeps every digest on the host.
     const bool gpu_md5 = getenv("ZWZ_HOST_MD5") == nullptr;
+    // A path may occur as two instances in one shard (finalised, then seen again: duplicate lines in the file list).  The reference
+    // handles records strictly in shard order, so the second instance re-opens (truncates) the file after the first is complete;
+    // here instances are written by concurrent tasks, so instances that share a path are taken out of the concurrency: each is
+    // written on this thread, behind everything submitted before it.
+    std::vector<bool> shared_path(insts.size(), false);
+    {
+        std::unordered_map<std::string, uint32_t> first;
+        for (uint32_t i = 0; i < insts.size(); i++) {
+            auto it = first.find(insts[i].rel);
+            if (it == first.end()) first.emplace(insts[i].rel, i);
+            else { shared_path[i] = true; shared_path[it->second] = true; }
+        }
+    }
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     double t_gpu_wait = 0, t_write_wait = 0;
@@ -790,7 +803,7 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
                 uint32_t e = g;
                 while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
                 OutState& o = outs[jobs[g].inst];
-                if (!o.deferred && e - g <= 64u && e - g == (uint32_t)insts[jobs[g].inst].order.size()) {
+                if (!o.deferred && !shared_path[jobs[g].inst] && e - g <= 64u && e - g == (uint32_t)insts[jobs[g].inst].order.size()) {
                     o.gpu_md5 = (int32_t)sl.n_md5[b];
                     sl.h_files[b][2 * sl.n_md5[b]] = g - g0; sl.h_files[b][2 * sl.n_md5[b] + 1] = e - g;
                     sl.n_md5[b]++;
@@ -842,7 +855,18 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
             while (e < g1 && jobs[e].inst == jobs[g].inst) e++;
             const uint32_t inst = jobs[g].inst, a0 = g, a1 = e;
             OutState& os = outs[inst];
-            if (!os.deferred) {
+            if (shared_path[inst]) {            // rare: in shard order, nothing else of this path in flight (see shared_path)
+                pool.wait(write_group); pool.wait(md5_group);
+                if (!os.f && !os.failed && os.remaining == (uint32_t)insts[inst].order.size()) open_out(inst);
+                for (uint32_t k = a0; k < a1; k++) {
+                    const uint8_t* src = sl.h_out[b] + (size_t)(k - g0) * ZWZ_DEV_STRIDE;
+                    const uint32_t n = sl.h_olen[b][k - g0];
+                    if (os.f) fwrite(src, 1, n, os.f);
+                    os.md5.update(src, n);
+                }
+                os.remaining -= a1 - a0;
+                if (os.remaining == 0) finish_out(inst, nullptr);
+            } else if (!os.deferred) {
                 pool.submit(write_group, [&, b, g0, inst, a0, a1] {
                     OutState& o = outs[inst];
                     if (!o.f && !o.failed) open_out(inst);

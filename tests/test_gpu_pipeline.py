@@ -386,3 +386,26 @@ def test_parallel_consumers_write_records_out_of_order(zwz, tmp_path, monkeypatc
         assert r.returncode == 0 and "MD5 mismatch" not in r.stderr and r.stdout.count("MD5 match") == len(files)
         for n, d in files.items():
             assert open(b3 / n, "rb").read() == d, n
+
+
+def test_a_path_that_occurs_twice_in_a_shard_is_written_in_shard_order(zwz, codec, golden_dir, tmp_path):
+    """A shard may hold a path as two instances (finalised, then seen again -- duplicate lines in the file list).  The reference
+    takes records strictly in shard order: the second instance truncates and rewrites the file.  Here files are written by
+    concurrent tasks, so instances that share a path are taken out of the concurrency: the tree must be the one
+    a single instance gives, each instance verified."""
+    import zwz_records
+    good = open(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), "rb").read()
+    recs = zwz_records.parse(good)
+    twice = [r for r in recs if r[0] in (b"hello.txt", b"text100k.txt")]
+    assert len(twice) >= 3
+    blob = zwz_records.serialise(recs + twice + [r for r in recs if r[0] == b"hello.txt"])
+    src, out = tmp_path / "in", tmp_path / "out"
+    src.mkdir(); out.mkdir()
+    (src / "compressed_0.zwz").write_bytes(blob)
+    want = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["1"]
+    bad = codec.do_decompression(str(src), str(out))
+    assert _tree_of(str(out)) == want["decoded"]
+    plain = tmp_path / "plain_in"; plain_out = tmp_path / "plain_out"
+    plain.mkdir(); plain_out.mkdir()
+    (plain / "compressed_0.zwz").write_bytes(good)
+    assert bad == codec.do_decompression(str(plain), str(plain_out))          # the repeated files verify: no further mismatches
