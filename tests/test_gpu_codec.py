@@ -57,6 +57,49 @@ def test_deflate_match_flavours_agree_with_oracle(codec, oracle, flavour, monkey
             assert g == oracle.payload(c), (flavour, kind, len(c))
 
 
+def test_band_path_fuzz_every_kind_and_collision_heavy_data(codec, oracle, monkeypatch):
+    """Every chunk through lz_sort + lz_place + lz_match_band (ZWZ_MATCH=band), on what the production choice would never send there
+    and on what strains its corners: random lengths around the tile size (5 632 sorted entries) and its multiples; alphabets
+    whose trigrams collide in zlib's 15-bit hash (mixed buckets: the 8-byte words start at the trigram) with long repeats on top
+    (every entry flagged, sharers' chains through every halo); short periods; runs; chunks stitched from different kinds (the
+    word format changes from tile to tile)."""
+    monkeypatch.setenv("ZWZ_MATCH", "band")
+    rs = corpus.splitmix64(90210, 4 * 160)
+    kinds = [k for k in corpus.KINDS if k != "lz"]
+    chunks = []
+    for i in range(60):
+        n = [5632, 5633, 5634, 5635, 5636, 11264, 11266, 11267, 16898, 61954, 61955][i % 11] + int(rs[4 * i] % 3) if i % 2 else int(rs[4 * i] % 65536)
+        chunks.append(corpus.make(kinds[int(rs[4 * i + 1] % len(kinds))], 41000 + i, min(n, 65535)))
+    for i in range(60, 90):                      # bytes 0x00 / 0x20 / 0x40 / 0x60 ... in the first two trigram bytes collide in the hash's upper bits
+        n = 20000 + int(rs[4 * i] % 45536)
+        a = (corpus.splitmix64(42000 + i, n) % 8).astype("uint8")
+        b = ((a & 3) << 5 | (a >> 2)).astype("uint8")                       # 8 symbols spread over bits 0 and 5..6
+        unit = b[: 40 + int(rs[4 * i + 1] % 200)].tobytes()
+        data = bytearray(b.tobytes())
+        for j in range(0, n - len(unit), 997 + int(rs[4 * i + 2] % 3000)):   # long repeats on top
+            data[j:j + len(unit)] = unit
+        chunks.append(bytes(data))
+    for i in range(90, 110):                     # short periods and runs with a defect now and then
+        n = 30000 + int(rs[4 * i] % 35536)
+        per = 1 + int(rs[4 * i + 1] % 7)
+        data = bytearray((corpus.random_bytes(43000 + i, per) * (n // per + 1))[:n])
+        for j in range(int(rs[4 * i + 2] % 500), n, 1500 + int(rs[4 * i + 3] % 4000)):
+            data[j] ^= 0x55
+        chunks.append(bytes(data))
+    for i in range(110, 140):                    # stitched: text, then bytes, then text ...
+        parts, total = [], 0
+        for j in range(4):
+            kind = ["text", "random", "lowent", "gradient", "skewed"][int(rs[4 * i + j] % 5)]
+            n = min(4000 + int((rs[4 * i + j] >> 20) % 20000), 65535 - total)
+            if n <= 0:
+                break
+            parts.append(corpus.make(kind, 44000 + 4 * i + j, n)); total += n
+        chunks.append(b"".join(parts))
+    got = codec.deflate_chunks(chunks)
+    bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
+    assert not bad, bad[:10]
+
+
 def test_deflate_ragged_batch_crosses_chunk_boundaries(codec, oracle):
     """One batch of 1500 chunks of every kind of length -- empty, shorter than a trigram, around lz_links' 2048-position
     block, around the 16 Ki tile, full -- in a shuffled order: with more chunks than CUs every persistent workgroup
