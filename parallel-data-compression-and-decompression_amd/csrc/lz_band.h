@@ -34,7 +34,9 @@ ZWZ_HD uint32_t band_hash(uint32_t w) { return w >> 16; }
 // (same bucket; not position 0, which reads back as NIL and ends any chain; nearer than MAX_DIST.)  Monotone along the
 // array: once an entry fails, every entry further back fails too.
 ZWZ_HD bool band_valid(uint32_t own, uint32_t c) {
-    return band_hash(c) == band_hash(own) && band_pos(c) != 0u && band_pos(own) - band_pos(c) < kMaxDist;
+    // (with equal buckets the words' difference IS the positions' difference: c precedes own in its bucket)
+    const uint32_t d = own - c;
+    return (own ^ c) < 0x10000u && d < kMaxDist && d != band_pos(own);
 }
 // The first candidate alone may sit at exactly MAX_DIST -- unless zlib's window has slid by then (lz_search's start test).
 ZWZ_HD bool band_first_at_max_dist(uint32_t own, uint32_t c) {
