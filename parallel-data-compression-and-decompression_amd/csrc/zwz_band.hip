@@ -18,7 +18,7 @@
 #include "zwz_device.h"
 
 #ifndef ZWZ_BAND_EXP
-#define ZWZ_BAND_EXP 0     // timing experiments only (tools/band_exp.sh): 1 = no second pass, 2 = no band loop, 4 = no candidate counts
+#define ZWZ_BAND_EXP 0     // timing experiments only (tools/band_exp.sh; the records are then not zlib's): 1 = no second pass, 2 = no band loop
 #endif
 
 // (ZWZ_BAND_EXP & 16: thread 0 of every workgroup adds the cycles it spent per phase, >> 8, to tickets[16 + phase]; launch_deflate
