@@ -10,16 +10,20 @@
 
 namespace zwz {
 
-struct TreeScratch {
+template <uint32_t kCapT>
+struct TreeScratchT {
     // heap entries pack (freq:16 | depth:6 | node:10): smaller(n,m) == (key(n) <= key(m)) on the
     // (freq, depth) part, which is exactly zlib's comparison
-    uint32_t heap[kHeapSize + 1];
-    uint16_t freq[kHeapSize];
-    uint16_t dad[kHeapSize];
-    uint8_t depth[kHeapSize];
-    uint8_t len[kHeapSize];
+    static constexpr uint32_t kCap = kCapT;      // zlib's HEAP_SIZE for this tree: 2 * elems + 1
+    uint32_t heap[kCapT + 1];
+    uint16_t freq[kCapT];
+    uint16_t dad[kCapT];
+    uint8_t depth[kCapT];
+    uint8_t len[kCapT];
     uint16_t bl_count[16];
 };
+using TreeScratch = TreeScratchT<kHeapSize>;                 // any of the three trees
+using BlTreeScratch = TreeScratchT<2 * kBLCodes + 1>;        // the code-length tree alone (the device's plan kernel: 0.4 KB of LDS)
 
 struct BlockCodes {
     uint8_t llen[kLCodes + 2];    // lit/len code lengths (0 = unused)
@@ -48,11 +52,12 @@ ZWZ_HD void heap_sift(uint32_t* heap, int heap_len, int k) {
 // zlib build_tree + gen_bitlen + gen_codes.  freq_in[0..elems) are the symbol counts; lens/codes
 // receive the result.  extra_bits(sym) / static_len_of(sym) feed opt_len / static_len.
 // Returns max_code.  opt_len/static_len are updated in place (may be decremented for forced codes).
-template <class ExtraFn, class StatFn>
-ZWZ_HD int build_tree(TreeScratch& s, const uint16_t* freq_in, int elems, int max_length, ExtraFn extra_bits,
+template <class Scratch, class ExtraFn, class StatFn>
+ZWZ_HD int build_tree(Scratch& s, const uint16_t* freq_in, int elems, int max_length, ExtraFn extra_bits,
                       StatFn static_len_of, bool has_static, uint8_t* lens, uint16_t* codes, uint32_t& opt_len,
                       uint32_t& static_len) {
-    int heap_len = 0, heap_max = (int)kHeapSize, max_code = -1;
+    constexpr int kCap = (int)Scratch::kCap;
+    int heap_len = 0, heap_max = kCap, max_code = -1;
     for (int n = 0; n < elems; n++) {
         s.freq[n] = freq_in[n];
         s.len[n] = 0;
@@ -66,7 +71,7 @@ ZWZ_HD int build_tree(TreeScratch& s, const uint16_t* freq_in, int elems, int ma
         if (has_static) static_len -= static_len_of((uint32_t)node);
     }
     for (int n = heap_len / 2; n >= 1; n--) heap_sift(s.heap, heap_len, n);
-    // the sorted tail shares the array with the heap (zlib's layout): heap[heap_max..kHeapSize)
+    // the sorted tail shares the array with the heap (zlib's layout): heap[heap_max..kCap)
     int node = elems;
     do {
         uint32_t en = s.heap[1];
@@ -89,7 +94,7 @@ ZWZ_HD int build_tree(TreeScratch& s, const uint16_t* freq_in, int elems, int ma
     for (int b = 0; b < 16; b++) s.bl_count[b] = 0;
     int overflow = 0, h;
     s.len[s.heap[heap_max]] = 0;
-    for (h = heap_max + 1; h < (int)kHeapSize; h++) {
+    for (h = heap_max + 1; h < kCap; h++) {
         uint32_t n = s.heap[h];
         int bits = s.len[s.dad[n]] + 1;
         if (bits > max_length) { bits = max_length; overflow++; }
@@ -130,6 +135,85 @@ ZWZ_HD int build_tree(TreeScratch& s, const uint16_t* freq_in, int elems, int ma
         codes[n] = l ? (uint16_t)bit_reverse(next_code[l]++, l) : 0;
     }
     return max_code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build_tree in pieces, for the device's plan stage (zwz_plan.hip): the heap is the only part of it that is a chain, so it
+// runs a lane per tree with nothing but the heap in LDS; everything before and behind it is done by a wave per block.
+//   heap_merge_all   zlib's heapify + merge loop over heap[1..heap_len] (entries freq << 16 | symbol, in symbol order:
+//                    build_tree's first loop).  Merge s = 0, 1, ... joins the two least nodes n_s, m_s into node
+//                    elems + s; on return heap[heap_len0 - s] = n_s | m_s << 16 (the slot the merge itself vacates) and
+//                    heap[1] is the root.  n_0, m_0, n_1, m_1, ... is zlib's sorted tail read from the top
+//                    (heap[HEAP_SIZE - 1] downwards), the order gen_bitlen's overflow repair walks.
+//   tree_fix_overflow  gen_bitlen's repair of an over-long tree, on the lengths the merges gave.
+//   rle_run          what scan_tree / send_tree make of ONE maximal run of equal lengths: runs are independent of each
+//                    other (a new run always differs from the last length flushed), so a lane per run emits them.
+ZWZ_HD void heap_merge_all(uint32_t* heap, uint32_t heap_len, uint32_t elems) {
+    for (int n = (int)heap_len / 2; n >= 1; n--) heap_sift(heap, (int)heap_len, n);
+    uint32_t node = elems;
+    while (heap_len >= 2u) {
+        const uint32_t en = heap[1];
+        heap[1] = heap[heap_len--];
+        heap_sift(heap, (int)heap_len, 1);
+        const uint32_t em = heap[1];
+        const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
+        heap[heap_len + 1u] = (en & 1023u) | (em & 1023u) << 16;
+        heap[1] = ((en >> 16) + (em >> 16)) << 16 | ((dn >= dm ? dn : dm) + 1u) << 10 | node++;
+        heap_sift(heap, (int)heap_len, 1);
+    }
+}
+
+// zlib's forced symbols: a tree with fewer than two used symbols gets symbol 0 / 1 (or 0 beside a lone larger one) with
+// count 1.  m / max_code: used symbols and the highest of them (-1: none); returns the forced symbols in node[0..n).
+ZWZ_HD uint32_t tree_forced_nodes(uint32_t& m, int& max_code, uint32_t node[2]) {
+    uint32_t n = 0;
+    while (m < 2u) { node[n++] = (uint32_t)(max_code < 2 ? ++max_code : 0); m++; }
+    return n;
+}
+
+// gen_bitlen's overflow repair.  bl_count[1..max_length] as counted on the capped lengths, overflow = nodes (leaves and
+// internal ones) deeper than max_length, pair(s) = n_s | m_s << 16, n_merges of them; rewrites len[] of the leaves.
+template <class PairFn, class CountT>
+ZWZ_HD void tree_fix_overflow(CountT* bl_count, int max_length, int overflow, PairFn pair, uint32_t n_merges, int max_code, uint8_t* len) {
+    do {
+        int bits = max_length - 1;
+        while (bl_count[bits] == 0) bits--;
+        bl_count[bits]--; bl_count[bits + 1] += 2; bl_count[max_length]--;
+        overflow -= 2;
+    } while (overflow > 0);
+    uint32_t h = 0;                                     // index into n_0, m_0, n_1, m_1, ...
+    for (int bits = max_length; bits != 0; bits--) {
+        int n = (int)bl_count[bits];
+        while (n != 0) {
+            const uint32_t pr = pair(h >> 1), m = (h & 1u) ? pr >> 16 : pr & 0xffffu;
+            h++;
+            if ((int)m > max_code) continue;
+            len[m] = (uint8_t)bits;
+            n--;
+        }
+    }
+    (void)n_merges;
+}
+
+// One maximal run of `c` equal code lengths `v` (c >= 1) as scan_tree / send_tree flush it; sink(sym, extra_val, extra_nbits).
+template <class Sink>
+ZWZ_HD void rle_run(uint32_t v, uint32_t c, Sink sink) {
+    if (v == 0u) {
+        for (; c >= 138u; c -= 138u) sink(18u, 127u, 7u);
+        if (c == 0u) return;
+        if (c < 3u) { do sink(0u, 0u, 0u); while (--c); }
+        else if (c <= 10u) sink(17u, c - 3u, 3u);
+        else sink(18u, c - 11u, 7u);
+        return;
+    }
+    if (c < 4u) { do sink(v, 0u, 0u); while (--c); return; }
+    sink(v, 0u, 0u);
+    if (c <= 7u) { sink(16u, c - 4u, 2u); return; }
+    sink(16u, 3u, 2u);
+    for (c -= 7u; c >= 6u; c -= 6u) sink(16u, 3u, 2u);
+    if (c == 0u) return;
+    if (c < 3u) { do sink(v, 0u, 0u); while (--c); }
+    else sink(16u, c - 3u, 2u);
 }
 
 // Code-length RLE over lens[0..max_code] (zlib scan_tree / send_tree).  sink(sym, extra_val,

@@ -67,7 +67,11 @@ static_assert(sizeof(BlockProbe) == 32 + 640, "BlockProbe layout");
 
 constexpr uint32_t kChosenOffset = 4096;   // bytes into a chunk's link array
 constexpr uint32_t kChosenCap = 21846;     // matches per chunk: fewer than 65535 / 3 + 1
-static_assert(kMaxBlocks * sizeof(BlockProbe) <= kChosenOffset && kChosenOffset + kChosenCap * 4 <= kLinkStride * 2, "links space: probes, then chosen records");
+// The plan stage's merge lists (zwz_plan.hip: plan_heap -> plan) sit at the end of the same space: per block the literal/length
+// tree's merges (<= 285 words), then the distance tree's (<= 29).
+constexpr uint32_t kPairsOffset = 98304, kPairLitWords = 288, kPairWords = 320;
+static_assert(kMaxBlocks * sizeof(BlockProbe) <= kChosenOffset && kChosenOffset + kChosenCap * 4 <= kPairsOffset &&
+              kPairsOffset + kMaxBlocks * kPairWords * 4 <= kLinkStride * 2, "links space: probes, then chosen records, then merge lists");
 
 struct DeflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;   // chunk bases 16-byte aligned
@@ -94,7 +98,7 @@ struct InflateArgs {
 };
 
 constexpr size_t kTicketBytes = 256;
-enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6 };   // indices into DeflateArgs::tickets
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7 };   // indices into DeflateArgs::tickets
 // lz_match on its own (ZWZ_MATCH=walk): a chunk four of whose five positions have a chain predecessor (lz_links' count) takes the sorted walk.
 __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
 // With the band kernels: lz_dense_list looks at a chunk's first kDenseSample positions and calls it chain-heavy -- sort + band --
@@ -116,6 +120,7 @@ hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which
 hipError_t launch_sort(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_place(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_match_band(const DeflateArgs& a, hipStream_t s);
+hipError_t launch_plan(const DeflateArgs& a, hipStream_t s);                             // zwz_plan.hip
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,
                             uint32_t* digests, hipStream_t s);

@@ -37,14 +37,7 @@
 
 namespace zwz {
 
-// a chunk's dead link space: its kMaxBlocks BlockProbes first, its chosen records from kChosenOffset on
-static __device__ __forceinline__ BlockProbe* probe_of(BlockProbe* probes_base, uint32_t g) {
-    uint8_t* region = reinterpret_cast<uint8_t*>(probes_base) + (size_t)(g / kMaxBlocks) * (kLinkStride * sizeof(uint16_t));
-    return reinterpret_cast<BlockProbe*>(region) + g % kMaxBlocks;
-}
-static __device__ __forceinline__ const BlockProbe* probe_of(const BlockProbe* probes_base, uint32_t g) {
-    return probe_of(const_cast<BlockProbe*>(probes_base), g);
-}
+// a chunk's dead link space: its kMaxBlocks BlockProbes first (zwz_plan.hip), its chosen records from kChosenOffset on, the plan stage's merge lists at the end
 static __device__ __forceinline__ uint32_t* chosen_of(const uint16_t* links, uint32_t chunk) {
     return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(links + (size_t)chunk * kLinkStride)) + kChosenOffset);
 }
@@ -1231,217 +1224,6 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
-// plan, in three launches.
-//   plan_probe (one wave per block): the stored-block shortcut's parallel half -- exact static_len /
-//       extra bits / used codes, and both histograms sorted ascending (by counting when every count is
-//       small, else by rank) -> BlockProbe.
-//   plan_cost  (one LANE per block): the optimal Huffman cost of the sorted counts by two-queue
-//       merge, 64 blocks per wave, then huff_core.h's shortcut_type.  The merge is a chain of
-//       ~m dependent steps; a wave per block spends them on one lane (and on the CU's one scalar
-//       issue slot per cycle when written with readlanes -- measured 560 cycles per step with 20
-//       such waves on a CU), a lane per block runs 64 chains in each instruction.
-//   plan       (one wave per block): blocks the shortcut did not settle get zlib's exact tree
-//       construction on lane 0 with its scratch in LDS.
-// Sorting: composite keys (count << 9 | symbol) make the order total, so a lane's rank is a plain
-// count of smaller keys; the keys are read back four per LDS access and compared against all of the
-// lane's (up to five) own keys at once.
-constexpr uint32_t kSortKeys = 288;   // kLCodes rounded up to a multiple of 4
-static __device__ __forceinline__ uint32_t wave_rank_sort(const uint16_t* freq, uint32_t n, uint32_t* keys, uint16_t* sorted) {
-    // ascending order of the non-zero counts (ties by symbol; any order gives the same cost) -> sorted[0..m), returns m
-    const uint32_t lane = lane_id();
-    const uint32_t n4 = (n + 3u) & ~3u;
-    uint32_t k[5], rank[5] = {0, 0, 0, 0, 0}, zeros = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < 5; r++) {
-        const uint32_t i = lane + 64u * r;
-        k[r] = i < n ? ((uint32_t)freq[i] << 9) | i : 0xffffffffu;
-        if (i < n4) keys[i] = k[r];
-        zeros += (uint32_t)__popcll(__ballot(i < n && (k[r] >> 9) == 0));
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const uint4* k4 = reinterpret_cast<const uint4*>(keys);
-    const uint32_t rounds = (n + 63u) / 64u;            // wave-uniform: own keys in use
-#pragma unroll 2
-    for (uint32_t j = 0; j < n4 / 4u; j++) {
-        const uint4 q = k4[j];
-#pragma unroll
-        for (uint32_t r = 0; r < 5; r++)
-            if (r < rounds) rank[r] += (uint32_t)(q.x < k[r]) + (uint32_t)(q.y < k[r]) + (uint32_t)(q.z < k[r]) + (uint32_t)(q.w < k[r]);
-    }
-#pragma unroll
-    for (uint32_t r = 0; r < 5; r++) {
-        const uint32_t i = lane + 64u * r;
-        if (i < n && (k[r] >> 9) != 0) sorted[rank[r] - zeros] = (uint16_t)(k[r] >> 9);
-    }
-    return n - zeros;
-}
-
-// The same order by counting when every count is small (a 16 383-symbol block of incompressible bytes: all of them
-// between ~30 and ~100): a 128-bin histogram of the counts by LDS atomics, a wave scan, and every lane writes out its
-// two bins -- ~100 instructions against the rank sort's ~3 000.  Returns m, or 0xffffffff if some count is >= 128.
-static __device__ __forceinline__ uint32_t wave_count_sort(const uint16_t* freq, uint32_t n, uint32_t* bins /* 128 */, uint16_t* sorted) {
-    const uint32_t lane = lane_id();
-    uint32_t f[5]; bool big = false;
-#pragma unroll
-    for (uint32_t r = 0; r < 5; r++) { const uint32_t i = lane + 64u * r; f[r] = i < n ? (uint32_t)freq[i] : 0u; big = big || f[r] >= 128u; }
-    if (__ballot(big)) return 0xffffffffu;
-    bins[lane] = 0; bins[lane + 64u] = 0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (uint32_t r = 0; r < 5; r++) if (f[r]) atomicAdd(&bins[f[r]], 1u);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t c0 = lane ? bins[2u * lane] : 0u, c1 = bins[2u * lane + 1u];     // bin 0 = unused symbols: not sorted
-    uint32_t incl = c0 + c1;
-    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-    uint32_t at = incl - c0 - c1;
-    for (uint32_t k = 0; k < c0; k++) sorted[at++] = (uint16_t)(2u * lane);
-    for (uint32_t k = 0; k < c1; k++) sorted[at++] = (uint16_t)(2u * lane + 1u);
-    return __shfl(incl, 63);
-}
-
-__global__ __launch_bounds__(64) void plan_probe_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
-                                                        BlockProbe* __restrict__ probes) {
-    __shared__ uint16_t lf[kLCodes + 2], df[kDCodes + 2];
-    __shared__ __attribute__((aligned(16))) uint32_t keys[kSortKeys];
-    const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
-    BlockProbe* pb = probe_of(probes, blockIdx.x);
-    const BlockInfo* bi = blocks + blockIdx.x;
-    if (b >= info[chunk].n_blocks) { if (threadIdx.x == 0) pb->state = kProbeNone; return; }
-    const uint32_t stored_len = bi->end - bi->start;
-    const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
-    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
-    if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
-    __syncthreads();
-    // exact static_len / extra bits / used codes: five symbols per lane, wave reduction
-    StoredProbe pr{0, 0, 0};
-    for (uint32_t n = threadIdx.x; n < kLCodes + kDCodes; n += 64) {
-        const bool lit = n < kLCodes;
-        const uint32_t f = lit ? lf[n] : df[n - kLCodes];
-        if (!f) continue;
-        const uint32_t x = lit ? (n >= 257u ? length_extra_bits(n - 257u) : 0u) : dist_extra_bits(n - kLCodes);
-        pr.static_len += f * ((lit ? static_lit_len(n) : 5u) + x); pr.extra_bits += f * x; pr.used++;
-    }
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        pr.static_len += __shfl_xor(pr.static_len, d); pr.extra_bits += __shfl_xor(pr.extra_bits, d); pr.used += __shfl_xor(pr.used, d);
-    }
-    uint32_t m_l = wave_count_sort(lf, kLCodes, keys, pb->lit);
-    if (m_l == 0xffffffffu) m_l = wave_rank_sort(lf, kLCodes, keys, pb->lit);
-    __syncthreads();
-    uint32_t m_d = wave_count_sort(df, kDCodes, keys, pb->dist);
-    if (m_d == 0xffffffffu) m_d = wave_rank_sort(df, kDCodes, keys, pb->dist);
-    if (threadIdx.x == 0) {
-        pb->static_len = pr.static_len; pb->extra_bits = pr.extra_bits; pb->used = pr.used;
-        pb->m_l = m_l; pb->m_d = m_d; pb->stored_len = stored_len; pb->stored_ok = stored_ok; pb->state = kProbeOpen;
-    }
-}
-
-// Two-queue merge on one lane, in place: a[0..m) ascending leaves.  Internal node k is written to
-// a[k]; that slot is always a leaf already consumed (after k merges 2k items are gone, of which at
-// most k were internal nodes, so at least k leaves -- and a step reads its inputs before it writes).
-// All lanes run the loop to `steps` = the wave's largest m; a lane is live while step < its own m.
-static __device__ __forceinline__ uint32_t lane_huffman_cost(uint16_t* a, uint32_t m, uint32_t steps) {
-    constexpr uint32_t kInf = 0x7fffffffu;
-    uint32_t li = 0, qi = 0, qn = 0, cost = 0;
-    for (uint32_t step = 1; step < steps; step++) {
-        if (step < m) {
-            const uint32_t l0 = li < m ? (uint32_t)a[li] : kInf, l1 = li + 1 < m ? (uint32_t)a[li + 1] : kInf;
-            const uint32_t q0 = qi < qn ? (uint32_t)a[qi] : kInf, q1 = qi + 1 < qn ? (uint32_t)a[qi + 1] : kInf;
-            // first = smaller head (leaf on ties), second = smaller of the heads left
-            const uint32_t tl = l0 <= q0 ? 1u : 0u;
-            const uint32_t first = tl ? l0 : q0, nl = tl ? l1 : l0, nq = tl ? q0 : q1;
-            const uint32_t t2 = nl <= nq ? 1u : 0u;
-            const uint32_t sum = first + (t2 ? nl : nq);
-            li += tl + t2; qi += 2u - tl - t2;
-            cost += sum;
-            a[qn++] = (uint16_t)sum;                    // <= 16384: the block's symbol count
-        }
-    }
-    return cost;
-}
-
-constexpr uint32_t kCostLaneWords = 161;   // 160 words of sorted counts per lane, odd stride against bank conflicts
-constexpr uint32_t kCostLanes = 16;        // blocks per wave: a lane's row is 644 bytes and the merge is a chain of LDS round trips per lane -- with 64
-                                           // rows a wave (41 KB) three waves a CU had nothing to hide them behind: 0.51 ms per 250 000 blocks,
-                                           // 32 rows 0.33, 16 rows (fifteen waves a CU) 0.30
-__global__ __launch_bounds__(64) void plan_cost_kernel(BlockProbe* __restrict__ probes, uint32_t n_blocks_total) {
-    __shared__ uint32_t arr[kCostLanes * kCostLaneWords];
-    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * kCostLanes;
-    const uint32_t g = g0 + lane;
-    const bool mine_ok = lane < kCostLanes && g < n_blocks_total;
-    BlockProbe* mine = probe_of(probes, mine_ok ? g : 0u);
-    const bool live = mine_ok && mine->state == kProbeOpen;
-    uint32_t m_l = 0, m_d = 0;
-    if (live) { m_l = mine->m_l; m_d = mine->m_d; }
-    // stage the sorted counts of every probed block of this wave: lane-private rows, coalesced copy
-    for (uint32_t j = 0; j < kCostLanes; j++) {
-        const uint32_t ml = __shfl(m_l, j), md = __shfl(m_d, j);
-        if (ml == 0) continue;                           // not a block (a block counts at least its end-of-block symbol)
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(probe_of(probes, g0 + j)->lit);
-        uint32_t* dst = arr + j * kCostLaneWords;
-        for (uint32_t w = lane; w < (ml + 1u) / 2u; w += 64) dst[w] = src[w];
-        if (lane < (md + 1u) / 2u) dst[144 + lane] = src[144 + lane];
-    }
-    __syncthreads();
-    uint32_t max_l = m_l, max_d = m_d;
-    for (uint32_t d = 32; d >= 1; d >>= 1) { max_l = max(max_l, (uint32_t)__shfl_xor(max_l, d)); max_d = max(max_d, (uint32_t)__shfl_xor(max_d, d)); }
-    uint16_t* row = reinterpret_cast<uint16_t*>(arr + (lane < kCostLanes ? lane : 0u) * kCostLaneWords);   // (lanes without a row have m = 0: they never touch it)
-    const uint32_t hl = lane_huffman_cost(row, m_l, max_l);
-    const uint32_t hd = lane_huffman_cost(row + 288, m_d, max_d);
-    if (live) {
-        const StoredProbe pr{mine->static_len, mine->extra_bits, mine->used};
-        const uint32_t t = shortcut_type(pr, hl, hd, mine->stored_len, mine->stored_ok != 0);
-        if (t != kShortNone) mine->state = t == kShortStored ? kProbeStored : kProbeStatic;
-    }
-}
-
-__global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ info, const BlockInfo* __restrict__ blocks,
-                                                  const BlockProbe* __restrict__ probes, BlockOut* __restrict__ plans) {
-    __shared__ TreeScratch ts;
-    __shared__ BlockCodes bc;
-    __shared__ uint32_t hdr[kHdrWords];
-    __shared__ uint16_t lf[kLCodes], df[kDCodes];
-    const uint32_t chunk = blockIdx.x / kMaxBlocks, b = blockIdx.x % kMaxBlocks;
-    if (b >= info[chunk].n_blocks) return;
-    const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks + b;
-    BlockOut* bo = plans + (size_t)chunk * kMaxBlocks + b;
-    const uint32_t last = b + 1 == info[chunk].n_blocks;
-    const BlockProbe* mine = probe_of(probes, blockIdx.x);
-    const uint32_t settled = mine->state;
-    if (settled == kProbeStored) {                      // codes are never read for stored blocks
-        if (threadIdx.x == 0) { bo->type = kStored; bo->hdr_bits = 3; bo->body_bits = 0; bo->eob_len = 0; bo->eob_code = 0; bo->hdr[0] = last; }
-        return;
-    }
-    if (settled == kProbeStatic) {                      // the static codes, written out so the encoder needs no special case
-        if (threadIdx.x == 0) {
-            bo->type = kStatic; bo->hdr_bits = 3; bo->body_bits = mine->static_len; bo->hdr[0] = (1u << 1) + last;
-            bo->eob_len = static_lit_len(256); bo->eob_code = static_lit_code(256);
-        }
-        for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) { bo->llen[i] = (uint8_t)static_lit_len(i); bo->lcode[i] = (uint16_t)static_lit_code(i); }
-        if (threadIdx.x < kDCodes) { bo->dlen[threadIdx.x] = 5; bo->dcode[threadIdx.x] = (uint16_t)bit_reverse(threadIdx.x, 5); }
-        return;
-    }
-    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) lf[i] = bi->lfreq[i];
-    if (threadIdx.x < kDCodes) df[threadIdx.x] = bi->dfreq[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) hdr[i] = 0;
-    __syncthreads();
-    const uint32_t stored_len = bi->end - bi->start;
-    const bool stored_ok = !(bi->flush_pos >= kSlidePos && bi->start < kWSize);
-
-    if (threadIdx.x == 0) {
-        BlockPlan bp = plan_block(ts, lf, df, stored_len, stored_ok, last, bc, hdr);
-        bo->type = bp.type; bo->hdr_bits = bp.hdr_bits; bo->body_bits = bp.body_bits;
-        bo->eob_len = bc.llen[256]; bo->eob_code = bc.lcode[256];
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kLCodes; i += 64) { bo->llen[i] = bc.llen[i]; bo->lcode[i] = bc.lcode[i]; }
-    if (threadIdx.x < kDCodes) { bo->dlen[threadIdx.x] = bc.dlen[threadIdx.x]; bo->dcode[threadIdx.x] = bc.dcode[threadIdx.x]; }
-    for (uint32_t i = threadIdx.x; i < kHdrWords; i += 64) bo->hdr[i] = hdr[i];
-}
-
-// ------------------------------------------------------------------------------------------------
 // encode: bit-pack one chunk's zlib stream into LDS, then stream the first <= 65535 bytes out.
 struct EncBlock { uint32_t type, hdr_pos, body_pos, body_bits, start, end, first_sym, eob_len, eob_code, sym_bits_before, data_byte; };
 
@@ -2355,9 +2137,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst,
                        a.info, a.blocks, a.links);
     if (ev) ZWZ_TRY(hipEventRecord(ev[4], s));
-    hipLaunchKernelGGL(plan_probe_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes);
-    hipLaunchKernelGGL(plan_cost_kernel, dim3((a.n * kMaxBlocks + kCostLanes - 1u) / kCostLanes), dim3(64), 0, s, a.probes, a.n * kMaxBlocks);
-    hipLaunchKernelGGL(plan_kernel, dim3(a.n * kMaxBlocks), dim3(64), 0, s, a.info, a.blocks, a.probes, a.plans);
+    ZWZ_TRY(launch_plan(a, s));
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     {
         uint32_t* huff_list = reinterpret_cast<uint32_t*>(a.perm);          // lz_match's work-order array is dead by now

@@ -33,6 +33,126 @@ uint32_t adler32(const uint8_t* d, uint32_t n) {
 }
 }  // namespace
 
+// ---- the plan stage's decomposition (csrc/zwz_plan.hip): heap_merge_all on a heap laid out in symbol order, depths by pointer
+// jumping over the merges, capped lengths + zlib's overflow repair, codes by rank, code-length runs one by one, header bits at
+// prefix sums.  Loops over "lanes" in place of the wave.  Compared field by field with plan_block (huff_core.h), which is the
+// specification and what the oracle comparison of the whole stream goes through.
+namespace {
+struct SplitTree { std::vector<uint8_t> len; std::vector<uint16_t> code; int max_code; };
+template <class ExtraFn, class StatFn>
+SplitTree split_tree(const uint16_t* freq_in, uint32_t E, ExtraFn extra_bits, StatFn static_len_of, uint32_t& opt_len, uint32_t& static_len) {
+    const uint32_t kMaxLen = 15;
+    std::vector<uint32_t> f(freq_in, freq_in + E), heap(E + 2, 0);
+    uint32_t m = 0; int maxc = -1;
+    for (uint32_t i = 0; i < E; i++) if (f[i]) { heap[++m] = f[i] << 16 | i; maxc = (int)i; }
+    uint32_t node[2] = {0, 0};
+    const uint32_t m0 = m, nf = tree_forced_nodes(m, maxc, node);
+    for (uint32_t k = 0; k < nf; k++) { heap[1 + m0 + k] = 1u << 16 | node[k]; opt_len--; static_len -= static_len_of(node[k]); f[node[k]] = 1; }
+    heap_merge_all(heap.data(), m, E);
+    const uint32_t nm = m - 1, root = nm - 1;
+    std::vector<uint32_t> pairs(nm), A(nm), D(nm);
+    for (uint32_t s = 0; s < nm; s++) pairs[s] = heap[m - s];
+    std::vector<uint32_t> par(nm);
+    for (uint32_t s = 0; s < nm; s++) par[s] = s;
+    for (uint32_t s = 0; s < nm; s++) { const uint32_t a = pairs[s] & 0xffff, b = pairs[s] >> 16; if (a >= E) par[a - E] = s; if (b >= E) par[b - E] = s; }
+    for (uint32_t s = 0; s < nm; s++) { A[s] = par[s]; D[s] = s != root ? 1 : 0; }
+    for (uint32_t round = 0; round < 6; round++) {
+        bool far = false;
+        for (uint32_t s = 0; s < nm; s++) far = far || A[s] != root;
+        if (!far) break;
+        std::vector<uint32_t> A0 = A, D0 = D;
+        for (uint32_t s = 0; s < nm; s++) { D[s] = D0[s] + D0[A0[s]]; A[s] = A0[A0[s]]; }
+    }
+    for (uint32_t s = 0; s < nm; s++) if (A[s] != root) { opt_len = 0xdeadbeef; }       // (a tree 64 deep: cannot happen)
+    SplitTree t; t.len.assign(E + 2, 0); t.code.assign(E + 2, 0); t.max_code = maxc;
+    uint32_t blc[16] = {0}, over = 0;
+    for (uint32_t s = 0; s < nm; s++) {
+        const uint32_t a = pairs[s] & 0xffff, b = pairs[s] >> 16, bits = D[s] + 1, capped = bits < kMaxLen ? bits : kMaxLen;
+        if (a < E) { t.len[a] = (uint8_t)capped; blc[capped]++; over += bits > kMaxLen; }
+        if (b < E) { t.len[b] = (uint8_t)capped; blc[capped]++; over += bits > kMaxLen; }
+        over += s != root && D[s] > kMaxLen;
+    }
+    if (over) tree_fix_overflow(blc, (int)kMaxLen, (int)over, [&](uint32_t s) { return pairs[s]; }, nm, maxc, t.len.data());
+    uint32_t nc[16], code = 0;
+    nc[0] = 0;
+    for (uint32_t b = 1; b <= 15; b++) { code = (code + blc[b - 1]) << 1; nc[b] = code; }
+    for (uint32_t i = 0; i < E; i++) {
+        const uint32_t l = t.len[i];
+        t.code[i] = l ? (uint16_t)bit_reverse(nc[l]++, l) : 0;
+        if (f[i]) { opt_len += f[i] * (l + extra_bits(i)); static_len += f[i] * (static_len_of(i) + extra_bits(i)); }
+    }
+    return t;
+}
+struct Run { uint32_t v, c; };
+std::vector<Run> runs_of(const std::vector<uint8_t>& len, int maxc) {
+    std::vector<Run> r;
+    for (int i = 0; i <= maxc; i++) { if (i == 0 || len[i] != len[i - 1]) r.push_back({len[i], 1}); else r.back().c++; }
+    return r;
+}
+// 0 if the split gives plan_block's results, else a code naming the first field that differs
+uint32_t split_vs_plan_block(const uint16_t* lfreq, const uint16_t* dfreq, uint32_t stored_len, bool stored_ok, uint32_t last) {
+    TreeScratch ts; BlockCodes bc; uint32_t hdr[kHdrWords] = {0};
+    const BlockPlan bp = plan_block(ts, lfreq, dfreq, stored_len, stored_ok, last, bc, hdr);
+    uint32_t opt_len = 0, static_len = 0;
+    const SplitTree lt = split_tree(lfreq, kLCodes, [](uint32_t n) { return n >= 257u ? length_extra_bits(n - 257u) : 0u; }, [](uint32_t n) { return static_lit_len(n); }, opt_len, static_len);
+    const SplitTree dt = split_tree(dfreq, kDCodes, [](uint32_t n) { return dist_extra_bits(n); }, [](uint32_t) { return 5u; }, opt_len, static_len);
+    if (lt.max_code != bc.l_max_code || dt.max_code != bc.d_max_code) return 1;
+    const std::vector<Run> lr = runs_of(lt.len, lt.max_code), dr = runs_of(dt.len, dt.max_code);
+    uint16_t blfreq[kBLCodes] = {0};
+    for (const auto* rs : {&lr, &dr}) for (const Run& r : *rs) rle_run(r.v, r.c, [&](uint32_t sym, uint32_t, uint32_t) { blfreq[sym]++; });
+    {   // the runs must be scan_tree's own emissions
+        uint16_t want[kBLCodes] = {0};
+        rle_lengths(lt.len.data(), lt.max_code, [&](uint32_t sym, uint32_t, uint32_t) { want[sym]++; });
+        rle_lengths(dt.len.data(), dt.max_code, [&](uint32_t sym, uint32_t, uint32_t) { want[sym]++; });
+        if (memcmp(want, blfreq, sizeof want)) return 2;
+    }
+    BlTreeScratch bts; uint8_t bllen[kBLCodes + 1]; uint16_t blcode[kBLCodes + 1]; uint32_t dummy = 0;
+    build_tree(bts, blfreq, (int)kBLCodes, 7, [](uint32_t n) { return n < 16u ? 0u : n == 16u ? 2u : n == 17u ? 3u : 7u; }, [](uint32_t) { return 0u; }, false, bllen, blcode, opt_len, dummy);
+    int mbi;
+    for (mbi = (int)kBLCodes - 1; mbi >= 3; mbi--) if (bllen[bl_order((uint32_t)mbi)] != 0) break;
+    opt_len += 3u * ((uint32_t)mbi + 1u) + 14u;
+    if (opt_len != bc.opt_len || static_len != bc.static_len) return 3;
+    uint32_t opt_lenb = (opt_len + 10u) >> 3; const uint32_t static_lenb = (static_len + 10u) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    uint32_t h2[kHdrWords] = {0};
+    BitSink sink{h2, 0};
+    uint32_t type;
+    if (stored_len + 4u <= opt_lenb && stored_ok) { type = kStored; sink.put(last, 3); }
+    else if (static_lenb == opt_lenb) { type = kStatic; sink.put(2u + last, 3); }
+    else {
+        type = kDynamic;
+        sink.put(4u + last, 3); sink.put((uint32_t)(lt.max_code - 256), 5); sink.put((uint32_t)dt.max_code, 5); sink.put((uint32_t)(mbi - 3), 4);
+        for (int r = 0; r <= mbi; r++) sink.put(bllen[bl_order((uint32_t)r)], 3);
+    }
+    uint32_t hdr_bits = sink.nbits;
+    if (type == kDynamic) {
+        auto or_bits = [&](uint32_t pos, uint32_t v, uint32_t n) { if (!n) return; h2[pos >> 5] |= v << (pos & 31); if ((pos & 31) + n > 32) h2[(pos >> 5) + 1] |= v >> (32 - (pos & 31)); };
+        for (const auto* rs : {&lr, &dr}) for (const Run& r : *rs) {
+            uint32_t pos = hdr_bits;                  // (the kernel: exclusive prefix sum of the runs' bit counts)
+            rle_run(r.v, r.c, [&](uint32_t sym, uint32_t xv, uint32_t xn) { or_bits(pos, (uint32_t)blcode[sym] | xv << bllen[sym], bllen[sym] + xn); pos += bllen[sym] + xn; });
+            hdr_bits = pos;
+        }
+    }
+    if (type != bp.type) return 4;
+    if (hdr_bits != bp.hdr_bits) return 5;
+    for (uint32_t i = 0; i < (hdr_bits + 31) / 32; i++) {
+        const uint32_t n = hdr_bits - 32 * i < 32 ? hdr_bits - 32 * i : 32, mask = n == 32 ? 0xffffffffu : (1u << n) - 1;
+        if ((h2[i] ^ hdr[i]) & mask) return 6;
+    }
+    const uint32_t body = type == kStored ? 0u : type == kStatic ? static_len : opt_len - (hdr_bits - 3u);
+    if (body != bp.body_bits) return 7;
+    if (type != kStatic) {
+        for (uint32_t i = 0; i < kLCodes; i++) if (lt.len[i] != bc.llen[i] || lt.code[i] != bc.lcode[i]) return 8;
+        for (uint32_t i = 0; i < kDCodes; i++) if (dt.len[i] != bc.dlen[i] || dt.code[i] != bc.dcode[i]) return 9;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" uint32_t emu_plan_split_check(const uint16_t* lfreq, const uint16_t* dfreq, uint32_t stored_len, int stored_ok, uint32_t last) {
+    return split_vs_plan_block(lfreq, dfreq, stored_len, stored_ok != 0, last);
+}
+
 extern "C" uint32_t emu_chunk_stream(const uint8_t* in, uint32_t L, uint8_t* out, uint32_t cap,
                                      uint32_t* e128_out, uint32_t* e32_out) {
     std::vector<uint8_t> data(L + 16, 0);
@@ -105,6 +225,7 @@ extern "C" uint32_t emu_chunk_stream(const uint8_t* in, uint32_t L, uint8_t* out
             g_shortcut_hits += certain == kShortStored; g_static_hits += certain == kShortStatic;
         }
         BlockPlan bp = plan_block(ts, lf[b].data(), df[b].data(), be - bs, stored_ok, last, bc, hdr);
+        if (split_vs_plan_block(lf[b].data(), df[b].data(), be - bs, stored_ok, last)) return 0xfffffffdu;   // the device's decomposition of the same
         if ((certain == kShortStored && bp.type != kStored) || (certain == kShortStatic && bp.type != kStatic)) return 0xfffffffeu;
         for (uint32_t i = 0; i < bp.hdr_bits; i += 32) {
             uint32_t n = bp.hdr_bits - i < 32 ? bp.hdr_bits - i : 32;

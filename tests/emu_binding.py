@@ -23,6 +23,8 @@ def load():
                                 ctypes.POINTER(ctypes.c_uint32)]
     lib.emu_band_records.restype = ctypes.c_uint32
     lib.emu_band_records.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_plan_split_check.restype = ctypes.c_uint32
+    lib.emu_plan_split_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
     lib.emu_parse_blocks_check.restype = ctypes.c_int
     lib.emu_parse_blocks_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
     return lib
@@ -33,6 +35,7 @@ def chunk_stream(lib, data: bytes) -> bytes:
     out = ctypes.create_string_buffer(cap)
     n = lib.emu_chunk_stream(data, len(data), out, cap, None, None)
     assert n != 0xFFFFFFFF, "block plan mispredicted the body size"
+    assert n != 0xFFFFFFFD, "the plan stage's decomposition (heap / depths / runs) disagrees with plan_block"
     return out.raw[:n]
 
 

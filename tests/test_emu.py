@@ -107,3 +107,47 @@ def test_banded_search_corners(emu):
         for tile, fmt in ((5632, -1), (5632, 0), (1024, -1)):
             got = _band(emu, data, tile, fmt)
             assert got[0] == want[0] and got[1] == want[1], (idx, tile, fmt)
+
+
+def test_plan_split_matches_plan_block_on_histograms(emu):
+    """csrc/zwz_plan.hip's decomposition of zlib's block flush (heap a lane per tree, depths by pointer jumping over the
+    merges, capped lengths + overflow repair, codes by rank, code-length runs one by one) against huff_core.h's plan_block on
+    histograms no corpus produces: Fibonacci-like counts (trees deeper than 15 -> gen_bitlen's repair), all-equal counts
+    (every tie-break is the heap's), one or two used symbols (forced nodes), long runs of equal lengths."""
+    import numpy as np
+    rs = np.random.RandomState(31337)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+
+    def check(lf, df, stored_len=60000, stored_ok=1, last=1):
+        lf = np.asarray(lf, dtype=np.uint16).copy(); df = np.asarray(df, dtype=np.uint16).copy()
+        lf[256] = 1
+        assert lf.size == 286 and df.size == 30
+        rc = emu.emu_plan_split_check(lf.ctypes.data, df.ctypes.data, stored_len, stored_ok, last)
+        assert rc == 0, (rc, lf.tolist(), df.tolist())
+
+    z286, z30 = np.zeros(286, np.int64), np.zeros(30, np.int64)
+    check(z286, z30, stored_len=0)                                   # an empty block: EOB alone, both trees forced
+    for sym in (0, 1, 2, 97, 255, 285):
+        a = z286.copy(); a[sym] = 5; check(a, z30)
+    for d in (0, 1, 2, 29):
+        a = z286.copy(); a[65:91] = 3; b = z30.copy(); b[d] = 7; check(a, b)
+    for k in (3, 8, 17, 20, 22):                                      # skewed: deeper than 15 from k = 17 on (total <= 16383)
+        a = z286.copy(); a[10:10 + k] = fib[:k]; check(a, z30)
+        a = z286.copy(); a[np.arange(k) * 7] = fib[:k][::-1]; b = z30.copy(); b[:min(k, 20)] = fib[:min(k, 20)]; check(a, b)
+    for c in (1, 2, 57, 58):                                          # all counts equal: full, ragged
+        check(np.full(286, c), np.full(30, c))
+        a = z286.copy(); a[:200:3] = c; check(a, z30)
+    for _ in range(400):
+        used = rs.randint(1, 287)
+        a = z286.copy()
+        idx = rs.choice(286, used, replace=False)
+        shape = rs.randint(0, 4)
+        vals = [rs.randint(1, 4, used), rs.randint(1, 60, used), (rs.pareto(1.1, used) * 3 + 1).astype(np.int64), rs.geometric(0.02, used)][shape]
+        a[idx] = np.minimum(vals, 16383 // max(used, 1) + 1)
+        b = z30.copy()
+        nd = rs.randint(0, 31)
+        if nd:
+            b[rs.choice(30, nd, replace=False)] = np.minimum((rs.pareto(1.0, nd) * 2 + 1).astype(np.int64), 500)
+        check(a, b, stored_len=int(rs.randint(0, 65536)), stored_ok=int(rs.randint(0, 2)), last=int(rs.randint(0, 2)))
