@@ -1426,10 +1426,15 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     const uint32_t* chosen = chosen_of(links, chunk);
     const uint64_t* gsym = sym + (size_t)chunk * kMaskWords;
     const uint64_t* gmst = mst + (size_t)chunk * kMaskWords;
-    // match ranks (cheaper to recompute than to round-trip through HBM): thread t holds mask words t of both masks, wave w's
-    // words are exactly its 4096-position segment below
-    const uint64_t mst_l = tid < nwords ? gmst[tid] : 0ull;   // kEncodeThreads == kMaskWords
-    const uint64_t sym_l = tid < nwords ? gsym[tid] : 0ull;
+    // match ranks (cheaper to recompute than to round-trip through HBM): the chunk's mask words are dealt out to the waves in equal
+    // contiguous shares -- lane l of wave w holds word w * wpw + l of both masks, the wave's segment below -- so that a short
+    // chunk keeps all sixteen waves busy (with fixed 4096-position segments a 7 KB chunk was two waves' work and cost what a
+    // 64 KB one did: 4.1 ms per 30 000 image-like files)
+    const uint32_t wpw = (nwords + kEncodeThreads / 64u - 1u) / (kEncodeThreads / 64u);       // words per wave: 64 for a full chunk
+    const uint32_t my_word = (tid >> 6) * wpw + lane_id();
+    const bool has_word = lane_id() < wpw && my_word < nwords;
+    const uint64_t mst_l = has_word ? gmst[my_word] : 0ull;
+    const uint64_t sym_l = has_word ? gsym[my_word] : 0ull;
     uint32_t mprefix;                                         // matches before this thread's word = its first index into `chosen`
     {
         const uint32_t mcnt = (uint32_t)__popcll(mst_l), mincl = wave_scan_incl(mcnt);
@@ -1525,7 +1530,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         }
     }
     {
-        // Symbols.  Wave w owns the contiguous positions [4096 w, 4096 w + 4096): a first pass adds up
+        // Symbols.  Wave w owns the contiguous positions [64 wpw w, 64 wpw (w + 1)): a first pass adds up
         // its code lengths, one barrier turns the 16 wave totals into start offsets, and the second
         // pass packs bits with wave-local scans only (a barrier per 1024 positions kept the single
         // resident workgroup of a CU waiting: 30 ms for 50k text chunks).
@@ -1537,7 +1542,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         // it is being worked on.  The records come from lz_parse's compact array (read from the position-indexed one, every
         // 64-byte line of its 512 KB held a match start and both passes fetched all of it: ~50 GB a pass on text).
         const uint32_t wave = tid >> 6, lane = lane_id();
-        const uint32_t seg = wave * 4096u, seg_end = min(seg + 4096u, L);
+        const uint32_t seg = min(wave * wpw * 64u, L), seg_end = min(seg + wpw * 64u, L);
         // blocks are contiguous position ranges: a position's block is the number of block starts at
         // or before it (holds for covered positions too: a block ends where its last symbol ends)
         const uint32_t b1 = ci.n_blocks > 1 ? s_blk[1].start : 0xffffffffu, b2 = ci.n_blocks > 2 ? s_blk[2].start : 0xffffffffu;

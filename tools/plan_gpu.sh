@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
 cd $R && timeout -k 10 700 python -m pytest tests/test_gpu_codec.py -m gpu -x -q > gpurun_out/plan_$TAG.log 2>&1; rc=$?
 tail -3 gpurun_out/plan_$TAG.log
 [ $rc -ne 0 ] && { echo "GPU TESTS FAILED rc=$rc"; tail -60 gpurun_out/plan_$TAG.log; exit $rc; }
-for mode in wave serial; do
+for mode in ${MODES:-wave}; do
   for w in "small_files --files 30000" "text --files 4000" "random --files 4000"; do
     ZWZ_PLAN=$mode timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $w > gpurun_out/plan_${TAG}_${mode}.json 2> gpurun_out/plan_${TAG}_${mode}.err || { echo "bench failed ($mode, $w)"; tail -20 gpurun_out/plan_${TAG}_${mode}.err; exit 1; }
     python3 - "$mode" "$w" gpurun_out/plan_${TAG}_${mode}.json <<'PY'
