@@ -38,13 +38,18 @@ struct BlockCodes {
 
 ZWZ_HD uint32_t heap_key(uint32_t e) { return e >> 10; }
 
+// pqdownheap.  Both sons are read at once and the chosen one is kept in hand (on the device: one LDS round trip a level, not
+// two dependent ones).  heap[heap_len + 1] is read beside the last son but never used: the array has that element (zlib's
+// sorted tail / the merge list start there).
 ZWZ_HD void heap_sift(uint32_t* heap, int heap_len, int k) {
-    uint32_t v = heap[k];
+    const uint32_t v = heap[k], kv = heap_key(v);
     int j = k << 1;
     while (j <= heap_len) {
-        if (j < heap_len && heap_key(heap[j + 1]) <= heap_key(heap[j])) j++;
-        if (heap_key(v) <= heap_key(heap[j])) break;
-        heap[k] = heap[j]; k = j; j <<= 1;
+        const uint32_t a = heap[j], b = heap[j + 1];
+        const bool right = j < heap_len && heap_key(b) <= heap_key(a);
+        const uint32_t c = right ? b : a;
+        if (kv <= heap_key(c)) break;
+        heap[k] = c; k = j + (int)right; j = k << 1;
     }
     heap[k] = v;
 }

@@ -5,7 +5,7 @@
 //   plan_cost    lane per block    optimal-Huffman-cost lower bound -> stored / static  } and tiny blocks never get trees; the
 //                                  settled, or the block goes onto the open list       } rest go onto a list
 //   plan_heap    LANE per tree     zlib's heap (heapify + merge loop, its tie-breaks are the heap's mechanics, so it is run as
-//                                  it is): sixty-four open blocks a wave, nothing but the heaps in LDS; the merges go to HBM
+//                                  it is): sixteen open blocks a wave, nothing but the heaps in LDS; the merges go to HBM
 //   plan         wave per block    everything else of build_tree / scan_tree / send_tree in wave-parallel form: depths by
 //                                  pointer jumping over the merges, lengths, length counts, codes (ranks by ordered LDS adds),
 //                                  code-length runs a lane each, header bits by prefix sum; the 19-symbol tree on one lane
@@ -260,11 +260,15 @@ __global__ __launch_bounds__(64) void plan_serial_kernel(const ChunkInfo* __rest
 
 
 // ------------------------------------------------------------------------------------------------
-// plan_heap: a lane per tree.  A workgroup takes 64 open blocks: its four waves lay the blocks' heaps out in LDS (build_tree's
-// first loop, wave-cooperative: used symbols in symbol order by ballot ranks; forced symbols behind), the first wave then
-// runs the 64 heaps, a lane each (huff_core.h: heap_merge_all), and all four copy the merges out.  Literal/length trees
-// first, then the distance trees in the same space.  Rows are an odd number of words apart.
-constexpr uint32_t kHeapLanes = 64, kHeapStride = 289, kHeapThreads = 256;
+// plan_heap: a lane per tree.  A one-wave workgroup takes 16 open blocks: it lays the blocks' heaps out in LDS (build_tree's
+// first loop, wave-cooperative: used symbols in symbol order by ballot ranks; forced symbols behind), runs the 16 heaps, a
+// lane each (huff_core.h: heap_merge_all), and copies the merges out.  Literal/length trees first, then the distance trees in
+// the same space.  Rows are an odd number of words apart.
+// What a launch costs is one heap's own chain -- ~3 800 sift levels for 256 used symbols, ~30 instructions and one LDS round trip
+// each, at a lone wave's issue rate: 0.63 ms -- times the rounds it takes to seat every workgroup; the heaps a CU holds at once
+// are bounded by the LDS either way (128), so rows per workgroup do not matter to the time (64 rows / 4 waves: 0.64 ms per 30 000
+// image-like blocks; 16 rows / 1 wave: 0.63) -- sixteen keeps a wave's lanes closer in trip count.
+constexpr uint32_t kHeapLanes = 16, kHeapStride = 289, kHeapThreads = 64;
 
 template <uint32_t E>
 static __device__ __forceinline__ uint32_t wave_heap_init(const uint32_t (&f)[(E + 63u) / 64u], uint32_t* h) {
