@@ -122,3 +122,41 @@ def golden_tree():
     for i in range(7):                                   # equal sizes: order = readdir + introsort
         files["same/eq%d.dat" % i] = low_entropy(200 + i, 1234)
     return files
+
+
+_DIST_BASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 32769]
+
+
+def deep_distance_tree(seed: int, k: int = 17, first_code: int = 13, margin: float = 0.02) -> bytes:
+    """A chunk whose last block's DISTANCE tree is deeper than 15 bits, so that zlib's gen_bitlen has to repair it: 32 KiB of
+    random bytes (two blocks of literals), then 4-byte copies of earlier 4-byte slots, each slot copied from at most once (the
+    match zlib finds is then the one intended), the distance codes drawn with counts w[i+2] = w[0] + ... + w[i] + 1 + 2 % --
+    a little steeper than Fibonacci, so the Huffman tree stays a chain when a handful of matches come out differently.
+    (tests/test_emu.py checks on the CPU that the repair is reached for the seeds the GPU test uses.)"""
+    import math
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    w = [1, 1]
+    while len(w) < k:
+        s = sum(w[:-1])
+        w.append(s + 1 + math.ceil(margin * s))
+    codes = np.repeat(np.arange(first_code, first_code + k), w)
+    rs.shuffle(codes)
+    out = bytearray(rs.randint(0, 256, 32768).astype(np.uint8).tobytes())
+    used = np.zeros(16384, dtype=bool)
+    last = -1
+    for c in codes:
+        c = int(c); p = len(out)
+        lo = _DIST_BASE[c]; hi = min(_DIST_BASE[c + 1] - 1, 32500, p)
+        slots = np.arange((p - hi + 3) // 4, (p - lo) // 4 + 1)
+        slots = slots[(~used[slots]) & (slots != last + 1)]          # never the slot right behind the last source: the two copies would be one match
+        rs.shuffle(slots)
+        for sl in slots:
+            sl = int(sl)
+            if last < 0 or out[4 * sl] != out[4 * last + 4]:        # ... and the previous match must not run on into this copy
+                break
+        else:
+            raise AssertionError((c, p))
+        used[sl] = True; last = sl
+        out += out[4 * sl:4 * sl + 4]
+    return bytes(out)

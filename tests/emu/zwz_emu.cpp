@@ -13,9 +13,12 @@
 
 using namespace zwz;
 
-static uint64_t g_shortcut_hits = 0, g_static_hits = 0;
+static uint16_t g_last_df[64][30]; static uint16_t g_last_lf[64][286]; static uint32_t g_last_nb = 0;
+extern "C" uint32_t emu_last_hist(uint16_t* lf, uint16_t* df, uint32_t b) { if (b < g_last_nb) { memcpy(lf, g_last_lf[b], 572); memcpy(df, g_last_df[b], 60); } return g_last_nb; }
+static uint64_t g_shortcut_hits = 0, g_static_hits = 0, g_overflow_hits = 0;
 extern "C" uint64_t emu_shortcut_hits() { return g_shortcut_hits; }
 extern "C" uint64_t emu_static_shortcut_hits() { return g_static_hits; }
+extern "C" uint64_t emu_overflow_hits() { return g_overflow_hits; }   // trees deeper than 15 that went through gen_bitlen's repair in the split form
 
 namespace {
 struct Out {
@@ -72,6 +75,7 @@ SplitTree split_tree(const uint16_t* freq_in, uint32_t E, ExtraFn extra_bits, St
         if (b < E) { t.len[b] = (uint8_t)capped; blc[capped]++; over += bits > kMaxLen; }
         over += s != root && D[s] > kMaxLen;
     }
+    g_overflow_hits += over != 0;
     if (over) tree_fix_overflow(blc, (int)kMaxLen, (int)over, [&](uint32_t s) { return pairs[s]; }, nm, maxc, t.len.data());
     uint32_t nc[16], code = 0;
     nc[0] = 0;
@@ -224,6 +228,7 @@ extern "C" uint32_t emu_chunk_stream(const uint8_t* in, uint32_t L, uint8_t* out
             certain = shortcut_type(probe_block(lf[b].data(), df[b].data()), hl, hd, be - bs, stored_ok);
             g_shortcut_hits += certain == kShortStored; g_static_hits += certain == kShortStatic;
         }
+        if (b < 64) { memcpy(g_last_lf[b], lf[b].data(), 572); memcpy(g_last_df[b], df[b].data(), 60); g_last_nb = b + 1; }
         BlockPlan bp = plan_block(ts, lf[b].data(), df[b].data(), be - bs, stored_ok, last, bc, hdr);
         if (split_vs_plan_block(lf[b].data(), df[b].data(), be - bs, stored_ok, last)) return 0xfffffffdu;   // the device's decomposition of the same
         if ((certain == kShortStored && bp.type != kStored) || (certain == kShortStatic && bp.type != kStatic)) return 0xfffffffeu;

@@ -128,13 +128,14 @@ def test_plan_split_matches_plan_block_on_histograms(emu):
         assert rc == 0, (rc, lf.tolist(), df.tolist())
 
     z286, z30 = np.zeros(286, np.int64), np.zeros(30, np.int64)
+    hits0 = emu.emu_overflow_hits()
     check(z286, z30, stored_len=0)                                   # an empty block: EOB alone, both trees forced
     for sym in (0, 1, 2, 97, 255, 285):
         a = z286.copy(); a[sym] = 5; check(a, z30)
     for d in (0, 1, 2, 29):
         a = z286.copy(); a[65:91] = 3; b = z30.copy(); b[d] = 7; check(a, b)
-    for k in (3, 8, 17, 20, 22):                                      # skewed: deeper than 15 from k = 17 on (total <= 16383)
-        a = z286.copy(); a[10:10 + k] = fib[:k]; check(a, z30)
+    for k in (3, 8, 17, 20, 22):                                      # skewed: deeper than 15 from k = 17 on (with the EOB's count of 1, fib[1:] makes the chain)
+        a = z286.copy(); a[10:10 + k] = fib[1:k + 1]; check(a, z30)
         a = z286.copy(); a[np.arange(k) * 7] = fib[:k][::-1]; b = z30.copy(); b[:min(k, 20)] = fib[:min(k, 20)]; check(a, b)
     for c in (1, 2, 57, 58):                                          # all counts equal: full, ragged
         check(np.full(286, c), np.full(30, c))
@@ -151,3 +152,15 @@ def test_plan_split_matches_plan_block_on_histograms(emu):
         if nd:
             b[rs.choice(30, nd, replace=False)] = np.minimum((rs.pareto(1.0, nd) * 2 + 1).astype(np.int64), 500)
         check(a, b, stored_len=int(rs.randint(0, 65536)), stored_ok=int(rs.randint(0, 2)), last=int(rs.randint(0, 2)))
+    assert emu.emu_overflow_hits() - hits0 >= 6          # the over-long trees (literal and distance) really went through the repair
+
+
+def test_deep_distance_tree_chunks_reach_the_repair(emu, oracle):
+    """corpus.deep_distance_tree: real chunks on which zlib's gen_bitlen must shorten an over-long distance tree -- the corner
+    tests/test_gpu_codec.py::test_plan_stage_skewed_histograms sends through the device's plan stage.  Here: the repair is
+    really reached (the split form counts it), and the cores give the oracle's stream."""
+    for seed in (2, 3, 4):
+        data = corpus.deep_distance_tree(seed)
+        h0 = emu.emu_overflow_hits()
+        assert emu_binding.chunk_stream(emu, data) == oracle.deflate6(data)
+        assert emu.emu_overflow_hits() - h0 >= 1, seed

@@ -57,6 +57,44 @@ def test_deflate_match_flavours_agree_with_oracle(codec, oracle, flavour, monkey
             assert g == oracle.payload(c), (flavour, kind, len(c))
 
 
+@pytest.mark.parametrize("mode", ["wave", "serial"])
+def test_plan_stage_skewed_histograms(codec, oracle, mode, monkeypatch):
+    """The block flush in its two device forms (csrc/zwz_plan.hip: a lane per heap + a wave per block, the default; ZWZ_PLAN=serial:
+    huff_core.h's plan_block on one lane) on symbol statistics the corpora never reach: geometric / Fibonacci-like byte
+    frequencies, a distance tree deeper than 15 bits (gen_bitlen's overflow repair), two-symbol and one-symbol chunks (forced
+    tree nodes), alphabets that leave long runs of zero and equal code lengths (scan_tree's 16 / 17 / 18 symbols), and
+    enough data per chunk for several blocks."""
+    import numpy as np
+    if mode == "serial":
+        monkeypatch.setenv("ZWZ_PLAN", "serial")
+    else:
+        monkeypatch.delenv("ZWZ_PLAN", raising=False)
+    rs = np.random.RandomState(777)
+    chunks = []
+    fib = [1, 1]
+    while len(fib) < 21:
+        fib.append(fib[-1] + fib[-2])
+    for k in (2, 3, 17, 19, 21):                       # shuffled bytes with Fibonacci frequencies: no matches to speak of, a deep tree
+        syms = rs.choice(256, k, replace=False)
+        body = np.repeat(syms, fib[:k]).astype(np.uint8)
+        for rep in (1, 2):
+            b = np.tile(body, rep)[:65535].copy(); rs.shuffle(b)
+            chunks.append(b.tobytes())
+    for p in (0.5, 0.2, 0.05):                         # geometric alphabets of different widths
+        for n in (3000, 20000, 65535):
+            chunks.append(np.minimum(rs.geometric(p, n) - 1, 255).astype(np.uint8).tobytes())
+    for n in (1, 2, 5, 300, 40000):                    # one symbol; two symbols
+        chunks.append(bytes([65]) * n)
+        chunks.append(rs.choice([3, 250], n).astype(np.uint8).tobytes())
+    for lo, hi in ((0, 4), (100, 103), (250, 256), (0, 256)):   # narrow alphabets at both ends: long zero runs in the length array
+        chunks.append(rs.randint(lo, hi, 50000).astype(np.uint8).tobytes())
+    chunks.append((np.arange(65535) % 251).astype(np.uint8).tobytes())          # every length equal: one long run
+    chunks += [corpus.deep_distance_tree(seed) for seed in (2, 3, 4)]           # a distance tree deeper than 15 bits: gen_bitlen's repair (reached: tests/test_emu.py)
+    got = codec.deflate_chunks(chunks)
+    for i, (c, g) in enumerate(zip(chunks, got)):
+        assert g == oracle.payload(c), (mode, i, len(c))
+
+
 def test_band_path_fuzz_every_kind_and_collision_heavy_data(codec, oracle, monkeypatch):
     """Every chunk through lz_sort + lz_place + lz_match_band (ZWZ_MATCH=band), on what the production choice would never send there
     and on what strains its corners: random lengths around the tile size (5 632 sorted entries) and its multiples; alphabets
