@@ -172,10 +172,10 @@ int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
     return ZWZ_OK;
 }
 
-void free_slices(Slices& s) {
-    for (auto& e : s.done) if (e) (void)hipEventDestroy(e);
-    if (s.md5_host) (void)hipHostFree(s.md5_host);
-    if (s.md5_dev) (void)hipFree(s.md5_dev);
+void free_slices(Slices& s) {                 // (idempotent: scope guards call it again behind the timed call of the normal path)
+    for (auto& e : s.done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (s.md5_host) { (void)hipHostFree(s.md5_host); s.md5_host = nullptr; }
+    if (s.md5_dev) { (void)hipFree(s.md5_dev); s.md5_dev = nullptr; }
 }
 
 // Waits for every listed task group when its scope is left, however that happens: tasks capture the enclosing function's
@@ -311,9 +311,21 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     int rc = make_slices(c, cap, sl);
     if (verbose()) fprintf(stderr, "zwz: staging for 2 x %u chunks allocated in %.3f s\n", cap,
                            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_alloc0);
-    if (rc) { close(dest); return rc; }
+    if (rc) { free_slices(sl); close(dest); return rc; }
     const uint32_t nslices = (T + cap - 1) / cap;
 
+    // Everything the pool's tasks reach by reference is declared BEFORE the Drain (destroyed after it has waited), the staging and
+    // the shard's descriptor under guards of their own: an exception on this thread (an allocation in a vector) then unwinds
+    // through a function whose tasks have finished and whose resources are released.
+    struct Rec { uint64_t off; uint32_t slot; int32_t path_len, seq, payload; uint8_t last; const std::string* rel; const char* md5; };
+    std::vector<Rec> recs;
+    std::vector<char> hexes;                     // digests that came back from the GPU as 16 raw bytes, as text
+    std::atomic<int> io_error{0}, write_error{0};
+    uint32_t truncated = 0;
+    uint64_t out_pos = 0;                        // shard bytes laid out so far
+    struct Release { Slices& sl; const int& fd; ~Release() { free_slices(sl); if (fd >= 0) close(fd); } };
+    int dest_open = dest;                        // -1 once the normal path has closed it
+    Release release{sl, dest_open};
     Pool::Group md5_group, read_group[2], write_group;
     Drain drain{pool, {&md5_group, &read_group[0], &read_group[1], &write_group}};
     // chunk g -> (file, chunk index in file): files are laid out back to back
@@ -322,7 +334,6 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
         while (lo < hi) { uint32_t mid = (lo + hi + 1) / 2; if (files[mid].first_chunk <= g) lo = mid; else hi = mid - 1; }
         return lo;
     };
-    std::atomic<int> io_error{0};
     auto hash_whole_file = [&](uint32_t fi) {     // md5_of_file(): re-read (verification.cpp:6-30)
         Md5 m;
         std::vector<uint8_t> buf(1 << 20);
@@ -443,13 +454,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     // slice's payload lengths are back: the caller's thread lays the slice out (and waits for the digests it needs),
     // then the pool writes it, each worker its own run of records with pwritev straight from the pinned output slots
     // -- a single buffered writer copied every payload twice and was the whole pipeline's pace (1.9 GB/s).
-    uint32_t truncated = 0;
-    uint64_t out_pos = 0;                        // shard bytes laid out so far
     const uint32_t consumers = [] { const char* v = getenv("ZWZ_CONSUMERS"); const long k = v ? atol(v) : 1; return (uint32_t)(k < 1 ? 1 : k > 64 ? 64 : k); }();
-    std::atomic<int> write_error{0};
-    struct Rec { uint64_t off; uint32_t slot; int32_t path_len, seq, payload; uint8_t last; const std::string* rel; const char* md5; };
-    std::vector<Rec> recs;
-    std::vector<char> hexes;                     // digests that came back from the GPU as 16 raw bytes, as text
     auto write_records = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(T, g0 + cap);
@@ -583,6 +588,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     free_slices(sl);
     if (verbose()) fprintf(stderr, "zwz: staging released in %.3f s\n", now() - t_free0);
     if (write_error.load() && rc == ZWZ_OK) { set_error("writing %s failed", out_path.c_str()); rc = ZWZ_E_IO; }
+    dest_open = -1;
     if (close(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
     mark("shard closed");
     if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed or vanished while it was being read"); rc = ZWZ_E_IO; }
@@ -764,8 +770,9 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
     Slices sl;
     int rc = make_slices(c, cap, sl);
-    if (rc) return rc;
+    if (rc) { free_slices(sl); return rc; }
     const uint32_t nslices = (T + cap - 1) / cap;
+    struct FreeSlices { Slices& s; ~FreeSlices() { free_slices(s); } } free_sl{sl};      // behind the Drain: released once the tasks are done, whatever the way out
     Pool::Group fill_group[2], write_group, md5_group;
     Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group, &md5_group}};
     // MD5 is one sequential stream per file (~0.65 GB/s).  A file decoded within one slice is hashed by the task that
@@ -964,13 +971,14 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     bool have_slices = false;
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, n ? (n + 1) / 2 + 1 : 1u)));
     const uint32_t nslices = (n + cap - 1) / cap;
-    auto cleanup = [&] {
+    auto cleanup = [&] {                         // (idempotent: also run by the guard below on any way out)
         (void)hipStreamSynchronize(c->stream);
         if (have_slices) free_slices(sl);
-        if (d_big) (void)hipFree(d_big);
-        if (d_lens) (void)hipFree(d_lens);
-        if (d_stat) (void)hipFree(d_stat);
+        if (d_big) { (void)hipFree(d_big); d_big = nullptr; }
+        if (d_lens) { (void)hipFree(d_lens); d_lens = nullptr; }
+        if (d_stat) { (void)hipFree(d_stat); d_stat = nullptr; }
     };
+    struct Cleanup { decltype(cleanup)& f; ~Cleanup() { f(); } } cleanup_guard{cleanup};
     if (n) {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)n * ZWZ_DEV_STRIDE);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
@@ -979,6 +987,10 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         if (e != hipSuccess) { (void)hipGetLastError(); set_error("record range of %u chunks does not fit device memory: %s", n, hipGetErrorString(e)); rc = ZWZ_E_NOMEM; }
         else { rc = make_slices(c, cap, sl); have_slices = rc == ZWZ_OK; }
     }
+    // (declared before the Drain -- destroyed after it has waited: the write tasks reach fds and cursor by reference)
+    std::vector<int> fds(insts.size(), -1);
+    struct CloseFds { std::vector<int>& v; ~CloseFds() { for (int& fd : v) if (fd >= 0) { close(fd); fd = -1; } } } close_fds{fds};
+    std::vector<uint64_t> cursor(insts.size(), 0);
     Pool::Group fill_group[2], write_group;
     Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group}};
     // ---- phase 1: payloads in, range inflated into d_big, only the decoded lengths come back
@@ -1022,7 +1034,6 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     }
     // Files are created (and truncated) by the rank that holds their first record, BEFORE the exchange: a rank that joins a
     // file further in opens it only afterwards, so no write can be lost to a late O_TRUNC.
-    std::vector<int> fds(insts.size(), -1);
     for (uint32_t g = j0; g < j1 && rc == ZWZ_OK; g++) {
         const uint32_t inst = jobs[g].inst;
         if (g != 0 && jobs[g - 1].inst == inst) continue;
@@ -1045,7 +1056,6 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     if (exchange(user, mine, all.data(), kFields) != 0) { cleanup(); set_error("rank exchange failed"); return ZWZ_E_IO; }
     for (int r = 0; r < nranks; r++) if (all[(size_t)r * kFields + 4]) { if (rc == ZWZ_OK) { set_error("rank %d failed while decoding its record range", r); rc = ZWZ_E_IO; } }
     // ---- phase 2: this rank's bytes to their places
-    std::vector<uint64_t> cursor(insts.size(), 0);
     if (rc == ZWZ_OK && n) {
         for (int r = 0; r < rank; r++)                      // what earlier ranks decoded into the file my range starts in
             if (all[(size_t)r * kFields + 2] == mine[0]) cursor[mine[0]] += all[(size_t)r * kFields + 3];
@@ -1077,7 +1087,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         }
         pool.wait(write_group);
     }
-    for (int fd : fds) if (fd >= 0) close(fd);
+    for (int& fd : fds) if (fd >= 0) { close(fd); fd = -1; }
     cleanup();
     // ---- barrier, then verification by whoever holds a file's last record
     uint64_t flag[1] = {(uint64_t)(rc != ZWZ_OK)};
