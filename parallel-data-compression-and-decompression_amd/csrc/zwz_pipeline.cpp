@@ -29,6 +29,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include <fcntl.h>
@@ -1150,7 +1152,22 @@ int decompress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, in
         std::vector<FileInst> insts;
         if (!parse_shard(blob, insts)) { damaged = true; if (rank == 0 || !split) fprintf(stderr, "Malformed shard (damaged from some record on): %s\n", shards[j].c_str()); }
         DecodeSink sink{dst_dir, insts, mismatches, log_mutex};
-        rc = split ? decode_shard_split(c, pool, blob, insts, sink, rank, nranks, exchange, user, ZWZ_OK) : decode_whole_shard(c, pool, blob, insts, sink);
+        // A path that occurs as two instances (duplicate lines in the file list) must be written in shard order, the later instance
+        // over the earlier (decode_whole_shard does that; the record-range split writes instances concurrently from several
+        // ranks).  Such a shard is not split: rank 0 decodes it whole, and every rank still goes through the split's two exchanges
+        // -- with nothing of its own -- so that a rank that could not even map the shard (above) meets the others there.
+        bool repeated_path = false;
+        if (split) {
+            std::unordered_set<std::string> seen;
+            for (const FileInst& fi : insts) if (!seen.insert(fi.rel).second) { repeated_path = true; break; }
+        }
+        if (split && repeated_path) {
+            int rc0 = rank == 0 ? decode_whole_shard(c, pool, blob, insts, sink) : ZWZ_OK;
+            std::vector<FileInst> none;
+            DecodeSink nothing{dst_dir, none, mismatches, log_mutex};
+            rc = decode_shard_split(c, pool, blob, none, nothing, rank, nranks, exchange, user, rc0);
+        } else
+            rc = split ? decode_shard_split(c, pool, blob, insts, sink, rank, nranks, exchange, user, ZWZ_OK) : decode_whole_shard(c, pool, blob, insts, sink);
         if (rc) break;
     }
     if (md5_mismatches) *md5_mismatches = mismatches.load();

@@ -409,3 +409,28 @@ def test_a_path_that_occurs_twice_in_a_shard_is_written_in_shard_order(zwz, code
     plain.mkdir(); plain_out.mkdir()
     (plain / "compressed_0.zwz").write_bytes(good)
     assert bad == codec.do_decompression(str(plain), str(plain_out))          # the repeated files verify: no further mismatches
+
+
+def test_cli_two_ranks_one_shard_with_a_repeated_path(golden_dir, tmp_path):
+    """ONE shard for two ranks is split into record ranges -- unless a path occurs in it twice: the later instance must be written
+    over the earlier in shard order, which ranks writing their ranges side by side cannot promise, so rank 0 decodes such a shard
+    whole and the others only keep the exchanges company.  The tree must be what a single instance of every file gives."""
+    import zwz_records
+    good = open(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), "rb").read()
+    recs = zwz_records.parse(good)
+    twice = [r for r in recs if r[0] in (b"hello.txt", b"text100k.txt")]
+    zdir = tmp_path / "zwz"
+    zdir.mkdir()
+    (zdir / "compressed_0.zwz").write_bytes(zwz_records.serialise(recs + twice))
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["1"]
+    back = tmp_path / "back"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS="2", ZWZ_DEVICE="0", ZWZ_RENDEZVOUS_TIMEOUT="120")
+        procs.append(subprocess.Popen([_cli(), "decompress", str(zdir), str(back)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rel, want in run["decoded"].items():
+        b = open(back / rel, "rb").read()
+        assert {"size": len(b), "sha256": sha(b)} == want, rel
+    assert sum(o[1].count("MD5 mismatch for file:") for o in outs) == run["md5_mismatches"]      # the repeated files verify
