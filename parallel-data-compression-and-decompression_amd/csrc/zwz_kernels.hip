@@ -35,6 +35,20 @@
 #include "zwz_kernels.h"
 #include "zwz_device.h"
 
+// (ZWZ_MATCH_EXP & 16, experiment builds only -- tools/match_times.sh: thread 0 of every lz_match workgroup sums the cycles it spent
+// per phase -- in registers: an atomic per stamp would be a VMEM operation the next vmcnt(0) waits for, which is what the first
+// version of this measured -- and adds them, >> 8, to tickets[40 + phase] at the end; launch_deflate prints them when
+// ZWZ_MATCH_TIMES is set.  Thread 0 is in the oldest wave of its SIMD, which the SIMD favours: the other waves' share of a phase shows
+// up as its "wait".)
+#ifndef ZWZ_MATCH_EXP
+#define ZWZ_MATCH_EXP 0
+#endif
+#if ZWZ_MATCH_EXP & 16
+#define ZWZ_MSTAMP(ph) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); acc_[(ph)] += (uint32_t)(now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define ZWZ_MSTAMP(ph) do { } while (0)
+#endif
+
 namespace zwz {
 
 // a chunk's dead link space: its kMaxBlocks BlockProbes first (zwz_plan.hip), its chosen records from kChosenOffset on, the plan stage's merge lists at the end
@@ -594,7 +608,8 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128,
                                                                  uint16_t* __restrict__ perms, const uint32_t* __restrict__ link_stat,
-                                                                 uint32_t band /* 0: every chunk is this kernel's, 1: chain-heavy chunks are lz_match_band's, 2: all are */) {
+                                                                 uint32_t band /* 0: every chunk is this kernel's, 1: chain-heavy chunks are lz_match_band's, 2: all are */,
+                                                                 uint32_t* __restrict__ mtimes /* experiment builds: phase cycles */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
     const uint32_t L = in_len[chunk];
@@ -636,6 +651,10 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     const bool sorted_order = band == 0u && chunk_is_dense(link_stat[chunk], L);  // workgroup-uniform (with the band kernels about, what gets here is sparse)
     for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
     uint32_t org = 0;
+#if ZWZ_MATCH_EXP & 16
+    uint64_t stamp_ = __builtin_amdgcn_s_memtime();
+    uint32_t acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     ZWZ_PREFETCH(0u)
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint32_t ts = t * kTile, te = min(ts + kTile, L);
@@ -647,6 +666,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             if (llo + tid + kMatchThreads < lhi) sl4[llo + tid + kMatchThreads - (org >> 3)] = pl1;
         }
         __syncthreads();
+        ZWZ_MSTAMP(t ? 6 : 0);                      // waiting for the tile's bytes and links, registers -> LDS (first tile: nothing hides the load)
         if (t + 1 < ntiles) ZWZ_PREFETCH(t + 1)     // in flight during the search below
 
         // Order of work inside the tile.  A group of 64 searches lasts as long as its longest chain, and chain lengths run
@@ -788,6 +808,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             uint16_t* wl = s_cnt + wave * kListCap;
             uint32_t nl = 0;                                                               // wave-uniform
             auto drain = [&](bool all) {                                 // all: the tile is over; else whole trips only, the rest waits
+                ZWZ_MSTAMP(1);                                           // screening so far
                 // The list is refined in place before it is searched, 64 entries a trip with every lane busy: an entry whose
                 // first two candidates both differ from it in the trigram's middle byte and have no third behind them cannot match (the
                 // walk would end on them with nothing found) -- on random bytes that is three entries in four, at a sixth
@@ -813,7 +834,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     if (keep) wl[ns + rank_in(m)] = (uint16_t)q;
                     ns += (uint32_t)__popcll(m);
                 }
+                ZWZ_MSTAMP(2);                                           // the list's refinement
                 for (uint32_t i = lane; i - lane < ns; i += 64u) search_and_store(i < ns ? ts + (uint32_t)wl[i] : ts, i < ns);
+                ZWZ_MSTAMP(3);                                           // the searches
                 const uint32_t rem = nl - n_proc;                            // < 64 entries go to the front and wait for company
                 const uint32_t keepq = lane < rem ? (uint32_t)wl[n_proc + lane] : 0u;
                 if (lane < rem) wl[lane] = (uint16_t)keepq;
@@ -868,7 +891,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             }
             drain(true);
         }
+        ZWZ_MSTAMP(1);
         __syncthreads();
+        ZWZ_MSTAMP(4);                              // waiting for the other waves
         for (uint32_t i = tid; i < ((npos + 63u) >> 6); i += kMatchThreads) {
             hm[(ts >> 6) + i] = (uint64_t)s_has[2 * i] | ((uint64_t)s_has[2 * i + 1] << 32);
             s_has[2 * i] = 0; s_has[2 * i + 1] = 0;                        // ready for the next tile (whoever read a word clears it)
@@ -896,9 +921,13 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) sl4[i] = rl[u]; }
             org = new_org;
         }
+        ZWZ_MSTAMP(5);                              // has128 out, the slide
     }
 #undef ZWZ_TILE_RANGE
 #undef ZWZ_PREFETCH
+#if ZWZ_MATCH_EXP & 16
+    if (tid == 0) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&mtimes[ph], acc_[ph] >> 8);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2126,7 +2155,13 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
-                       a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u);
+                       a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u, a.tickets + 40);
+    if ((ZWZ_MATCH_EXP & 16) && getenv("ZWZ_MATCH_TIMES")) {
+        uint32_t h[64];
+        ZWZ_TRY(hipStreamSynchronize(s));
+        ZWZ_TRY(hipMemcpy(h, a.tickets, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "ZWZ_MATCH_TIMES n=%u stage0=%u stage=%u screen=%u refine=%u search=%u wait=%u flush_slide=%u\n", a.n, h[40], h[46], h[41], h[42], h[43], h[44], h[45]);
+    }
     if (which != 1u) {
         ZWZ_TRY(launch_match_band(a, s));
         if (getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads

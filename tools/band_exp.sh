@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; F=${2:-2000}
 cd $R/parallel-data-compression-and-decompression_amd
 for X in $1; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -DZWZ_BAND_EXP=$X -shared -o libzwz_hip.so csrc/zwz_kernels.hip csrc/zwz_band.hip csrc/zwz_api.cpp csrc/zwz_host.cpp csrc/zwz_pipeline.cpp 2> /dev/null || { echo build failed; exit 1; }
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -DZWZ_BAND_EXP=$X -shared -o libzwz_hip.so csrc/zwz_kernels.hip csrc/zwz_band.hip csrc/zwz_plan.hip csrc/zwz_api.cpp csrc/zwz_host.cpp csrc/zwz_pipeline.cpp 2> /dev/null || { echo build failed; exit 1; }
   (cd /tmp && export TMPDIR=/tmp && O=$R/gpurun_out/bandexp_$X && mkdir -p $O && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload text --files $F > $O/trace.log 2>&1
    python3 - <<PY
 import csv, glob, collections
