@@ -167,6 +167,57 @@ ZWZ_HD bool inflate_block_type(InflateState& st, uint32_t& type) {
     return true;
 }
 
+// A dynamic block's header in pieces (the device builds the three tables with the whole wave between them, see inflate_kernel;
+// inflate_block_rest below strings them together for one thread):
+//   inflate_dyn_begin    HLIT / HDIST / HCLEN and the code-length code's lengths -> cl[19]
+//   inflate_dyn_lengths  the nlen + ndist code lengths (RLE symbols 16 / 17 / 18) through the code-length code's table, which
+//                        sits in the distance-table slots -> lens[]
+//   inflate_table_ok     zlib's verdict on a literal/length or distance code: over-subscribed never; incomplete only as a
+//                        single one-bit code (literal/length) / at most one code (distance)
+ZWZ_HD bool inflate_dyn_begin(InflateState& st, uint8_t* cl /* 19 */, uint32_t& nlen, uint32_t& ndist) {
+    BitReader& br = st.br;
+    uint32_t ncode, v;
+    if (br.bits < 14) br.refill();
+    if (br.bits < 14) { st.status = kInfNeedInput; return false; }
+    br.take(5, nlen); br.take(5, ndist); br.take(4, ncode);
+    nlen += 257; ndist += 1; ncode += 4;
+    if (nlen > 286 || ndist > 30) { st.status = kInfDataError; return false; }
+    for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
+    for (uint32_t i = 0; i < ncode; i++) {
+        if (!br.take(3, v)) { st.status = kInfNeedInput; return false; }
+        uint32_t o = i < 3 ? 16u + i : i == 3 ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
+        cl[o] = (uint8_t)v;
+    }
+    return true;
+}
+
+ZWZ_HD bool inflate_dyn_lengths(InflateState& st, const InflateTables& t, uint8_t* lens, uint32_t nlen, uint32_t ndist) {
+    BitReader& br = st.br;
+    uint32_t have = 0;
+    while (have < nlen + ndist) {
+        BitReader save = br;
+        int sym = decode_symbol(br, t.dist_fast, 7, t.dist_count, t.dist_sym);
+        if (sym == -1) { st.status = kInfNeedInput; return false; }
+        if (sym == -2) { st.status = kInfDataError; return false; }
+        if (sym < 16) { lens[have++] = (uint8_t)sym; continue; }
+        uint32_t prev = 0, rep, xb = sym == 16 ? 2u : sym == 17 ? 3u : 7u, xv;
+        if (!br.take(xb, xv)) { br = save; st.status = kInfNeedInput; return false; }
+        if (sym == 16) {
+            if (have == 0) { st.status = kInfDataError; return false; }
+            prev = lens[have - 1]; rep = 3u + xv;
+        } else rep = (sym == 17 ? 3u : 11u) + xv;
+        if (have + rep > nlen + ndist) { st.status = kInfDataError; return false; }
+        while (rep--) lens[have++] = (uint8_t)prev;
+    }
+    if (lens[256] == 0) { st.status = kInfDataError; return false; }
+    return true;
+}
+
+ZWZ_HD bool inflate_table_ok(InflateState& st, int rc, uint32_t max_len, bool literal) {
+    if (rc < 0 || (rc > 0 && (literal ? max_len != 1 : max_len > 1))) { st.status = kInfDataError; return false; }
+    return true;
+}
+
 ZWZ_HD uint32_t inflate_block_rest(InflateState& st, InflateTables* tp, uint8_t* lens, uint32_t v, uint32_t& src_off, uint32_t& len);
 
 ZWZ_HD uint32_t inflate_block_header(InflateState& st, InflateTables& t, uint8_t* lens /* 320 B scratch */,
@@ -208,42 +259,15 @@ ZWZ_HD uint32_t inflate_block_rest(InflateState& st, InflateTables* tp, uint8_t*
         build_decode_table(lens + 288, 30, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len, t.dist_walk);
         return kBlkHuffman;
     }
-    uint32_t ncode;
-    if (br.bits < 14) br.refill();
-    if (br.bits < 14) { st.status = kInfNeedInput; return kBlkStop; }
-    br.take(5, nlen); br.take(5, ndist); br.take(4, ncode);
-    nlen += 257; ndist += 1; ncode += 4;
-    if (nlen > 286 || ndist > 30) { st.status = kInfDataError; return kBlkStop; }
     uint8_t cl[19];
-    for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
-    for (uint32_t i = 0; i < ncode; i++) {
-        if (!br.take(3, v)) { st.status = kInfNeedInput; return kBlkStop; }
-        uint32_t o = i < 3 ? 16u + i : i == 3 ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
-        cl[o] = (uint8_t)v;
-    }
+    if (!inflate_dyn_begin(st, cl, nlen, ndist)) return kBlkStop;
     // the code-length code reuses the distance-table slots (7-bit fast index fits in 8)
     if (build_decode_table(cl, 19, t.dist_fast, 7, t.dist_count, t.dist_sym, max_len) != 0) { st.status = kInfDataError; return kBlkStop; }
-    uint32_t have = 0;
-    while (have < nlen + ndist) {
-        BitReader save = br;
-        int sym = decode_symbol(br, t.dist_fast, 7, t.dist_count, t.dist_sym);
-        if (sym == -1) { st.status = kInfNeedInput; return kBlkStop; }
-        if (sym == -2) { st.status = kInfDataError; return kBlkStop; }
-        if (sym < 16) { lens[have++] = (uint8_t)sym; continue; }
-        uint32_t prev = 0, rep, xb = sym == 16 ? 2u : sym == 17 ? 3u : 7u, xv;
-        if (!br.take(xb, xv)) { br = save; st.status = kInfNeedInput; return kBlkStop; }
-        if (sym == 16) {
-            if (have == 0) { st.status = kInfDataError; return kBlkStop; }
-            prev = lens[have - 1]; rep = 3u + xv;
-        } else rep = (sym == 17 ? 3u : 11u) + xv;
-        if (have + rep > nlen + ndist) { st.status = kInfDataError; return kBlkStop; }
-        while (rep--) lens[have++] = (uint8_t)prev;
-    }
-    if (lens[256] == 0) { st.status = kInfDataError; return kBlkStop; }
+    if (!inflate_dyn_lengths(st, t, lens, nlen, ndist)) return kBlkStop;
     int lr = build_decode_table(lens, nlen, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym, max_len, t.lit_walk);
-    if (lr < 0 || (lr > 0 && max_len != 1)) { st.status = kInfDataError; return kBlkStop; }
+    if (!inflate_table_ok(st, lr, max_len, true)) return kBlkStop;
     int dr = build_decode_table(lens + nlen, ndist, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym, max_len, t.dist_walk);
-    if (dr < 0 || (dr > 0 && max_len > 1)) { st.status = kInfDataError; return kBlkStop; }
+    if (!inflate_table_ok(st, dr, max_len, false)) return kBlkStop;
     return kBlkHuffman;
 }
 

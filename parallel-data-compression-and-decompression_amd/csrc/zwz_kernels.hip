@@ -1667,11 +1667,119 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
 // The payload comes through a 2 KiB LDS ring refilled 1 KiB at a time by the whole wave (16 bytes per lane,
 // coalesced): a round consumes < 1 KiB, so topping the ring up to pos + 1 KiB before every round keeps the
 // decoders off global memory entirely.
+// (ZWZ_INF_EXP & 16, experiment builds only -- tools/inflate_times.sh: every wave sums the cycles it spent per phase of the Huffman
+// branch in registers and adds them, >> 8, to g_inf_times[] at its end; launch_inflate prints them when ZWZ_INF_TIMES is set)
+#ifndef ZWZ_INF_EXP
+#define ZWZ_INF_EXP 0
+#endif
+#if ZWZ_INF_EXP & 16
+__device__ unsigned long long g_inf_times[8];
+#define ZWZ_ISTAMP(ph) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); iacc_[(ph)] += (uint32_t)(now_ - istamp_); istamp_ = now_; } while (0)
+#else
+#define ZWZ_ISTAMP(ph) do { } while (0)
+#endif
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
 constexpr uint32_t kWinParts = 2;          // windows a round may look at
 
 constexpr uint32_t kOwnCap = 1024;         // batch bytes the per-byte owner map covers (a batch is <= 64 symbols: ~300 bytes on text)
+
+// build_decode_table (inflate_core.h) by the whole wave, same tables and return value: per-length counts by LDS adds, the canonical
+// bookkeeping (Kraft sum, offsets, first codes: fifteen steps) by every lane alike, each symbol's place in sorted[] as one
+// ds_add_rtn a trip -- lanes in lane order, trips in program order: symbol order, the property zwz_ctx_create checks -- which is
+// also its rank among the codes of its length, so every lane knows its symbols' codes and fills their fast-table entries itself.
+// (On lane 0 alone a block's three tables were 0.5 M cycles: 7 % of inflate on text, 31 % on 7 KB files.)
+static __device__ __forceinline__ int wave_build_decode_table(const uint8_t* lens, uint32_t n /* <= 320 */, uint16_t* fast /* 16-byte aligned */, uint32_t fast_bits,
+                                                              uint16_t* count, uint16_t* sorted, uint32_t& max_len, uint16_t* walk0, uint32_t* scr /* 48 words */) {
+    const uint32_t lane = lane_id();
+    uint32_t* s_cnt = scr; uint32_t* s_pos = scr + 16; uint32_t* s_fc = scr + 32;
+    uint32_t l[5];
+#pragma unroll
+    for (uint32_t r = 0; r < 5; r++) { const uint32_t i = lane + 64u * r; l[r] = i < n ? (uint32_t)lens[i] : 0u; }
+    if (lane < 16u) s_cnt[lane] = 0;
+    for (uint32_t x = lane; x < (1u << fast_bits) / 8u; x += 64u) reinterpret_cast<uint4*>(fast)[x] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (uint32_t r = 0; r < 5; r++) if (l[r]) atomicAdd(&s_cnt[l[r]], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int left = 1;
+    uint32_t first = 0, index = 0, off = 0, code = 0, my_off = 0, my_fc = 0, my_cnt = 0;
+    max_len = 0;
+    for (uint32_t len = 1; len < 16u; len++) {
+        const uint32_t c = s_cnt[len];
+        if (c) max_len = len;
+        left = (left << 1) - (int)c;
+        if (left < 0) return -1;                                   // (wave-uniform)
+        if (len <= fast_bits) { index += c; first += c; first <<= 1; }
+        if (lane == len) { my_off = off; my_fc = code; my_cnt = c; }
+        off += c; code = (code + c) << 1;
+    }
+    if (lane < 16u) { s_pos[lane] = my_off; s_fc[lane] = my_fc | my_off << 16; count[lane] = (uint16_t)my_cnt; }   // (lane 0: zeros, as build_decode_table's count[0])
+    if (walk0 && lane == 0) { walk0[0] = (uint16_t)first; walk0[1] = (uint16_t)index; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (uint32_t r = 0; r < 5; r++) {
+        if (l[r]) {
+            const uint32_t i = lane + 64u * r, pos = atomicAdd(&s_pos[l[r]], 1u);
+            sorted[pos] = (uint16_t)i;
+            if (l[r] <= fast_bits) {
+                const uint32_t w = s_fc[l[r]], cd = (w & 0xffffu) + (pos - (w >> 16));
+                const uint16_t e = (uint16_t)((i << 4) | l[r]);
+                for (uint32_t j = bit_reverse(cd, l[r]); j < (1u << fast_bits); j += 1u << l[r]) fast[j] = e;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return left > 0 ? 1 : 0;
+}
+
+// inflate_dyn_lengths (inflate_core.h) by the whole wave: the code-length symbols are a Huffman stream of their own (codes <= 7 bits,
+// up to 7 extra bits), so they are decoded the way the block's symbols are -- every lane decodes the symbol that would start at its
+// bit of a 64-bit window, a scalar hop marks the real starts -- and the run lengths (16: repeat the last length, 17 / 18: zeros)
+// are expanded from a prefix sum.  Returns the bit position behind the last length, or 0xffffffff when anything is out of the
+// ordinary (input that ends, a repeat with nothing before it, a run past the end): the caller then lets lane 0 run the
+// sequential function from where the reader stands, which also gives zlib's exact verdict.  lens[] is only complete on success.
+static __device__ __forceinline__ uint32_t wave_dyn_lengths(const uint8_t* ring, uint32_t bp, uint32_t total_bits, const uint16_t* cl_fast /* 7-bit */,
+                                                            uint8_t* lens, uint32_t want /* nlen + ndist */) {
+    const uint32_t lane = lane_id();
+    uint32_t have = 0, carry = 0xffffffffu;                 // lengths written; the last length written (none yet)
+    while (have < want) {
+        const uint32_t a = bp + lane;
+        const uint32_t byte = (a >> 3) & (kInfRing - 1u);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(ring) + (byte >> 2);
+        const uint32_t bits = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u) >> (a & 7u);     // >= 25 valid bits
+        const uint32_t e = cl_fast[bits & 127u], l = e & 15u, sym = e >> 4;
+        const uint32_t xb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u, nb = l + xb;
+        const uint32_t xv = (bits >> l) & ((1u << xb) - 1u);
+        const bool bad = e == 0u || a + nb > total_bits;
+        // the real symbols: the orbit of offset 0 under "offset + bits of the symbol decoded there"
+        const uint32_t jr = lane + (nb ? nb : 1u);               // (strictly forward whatever the table holds: the hop below must end)
+        uint64_t M = 0; uint32_t at = 0;
+        while (at < 64u) { M |= 1ull << at; at = (uint32_t)__builtin_amdgcn_readlane((int)jr, (int)at); }
+        const bool mine = (M >> lane) & 1ull;
+        if (__ballot(mine && bad)) return 0xffffffffu;
+        const uint32_t rep = !mine ? 0u : sym < 16u ? 1u : sym == 18u ? 11u + xv : 3u + xv;
+        const uint32_t incl = wave_scan_incl(rep), before = have + incl - rep;
+        // the header ends exactly at `want`: symbols from there on are the block's own
+        const uint64_t over = __ballot(mine && before + rep > want), in_hdr = __ballot(mine && before < want);
+        if (over & in_hdr) return 0xffffffffu;                   // a run that crosses the end
+        const bool live = mine && before < want;
+        // what a 16 repeats: the length written last before it -- by the nearest earlier symbol that is not a 16 (17 / 18: zero), else the carry
+        const uint32_t def = live && sym != 16u ? lane + 1u : 0u;
+        const uint32_t near = wave_scan_max_incl(def);           // inclusive: a 16 contributes nothing, so it sees the nearest definer before it
+        const uint32_t dval = sym < 16u ? sym : 0u;
+        const uint32_t pv = near ? (uint32_t)__shfl((int)dval, (int)(near - 1u)) : carry;
+        const uint32_t val = sym == 16u ? pv : dval;
+        if (__ballot(live && sym == 16u && pv == 0xffffffffu)) return 0xffffffffu;   // a repeat with nothing before it
+        if (live) for (uint32_t k = 0; k < rep; k++) lens[before + k] = (uint8_t)val;
+        const uint64_t lv = __ballot(live);
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(lv);                // lv != 0: offset 0 is always live here
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)last);
+        have = (uint32_t)__builtin_amdgcn_readlane((int)(before + rep), (int)last);
+        bp += (uint32_t)__builtin_amdgcn_readlane((int)jr, (int)last);
+    }
+    return bp;
+}
 
 struct InflateWaveMem {
     InflateTables t;
@@ -1717,6 +1825,10 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
     };
 
     InflateState st;
+#if ZWZ_INF_EXP & 16
+    uint64_t istamp_ = __builtin_amdgcn_s_memtime();
+    uint32_t iacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     top_up(0);
     uint32_t go = 0;
     if (lane == 0) go = inflate_begin(st, m.ring, nin, kInfRing - 1u) ? 1u : 0u;
@@ -1725,7 +1837,54 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
     while (go) {
         uint32_t kind = kBlkStop, soff = 0, slen = 0, opos = 0;
         top_up(st.br.pos);
-        if (lane == 0) { opos = st.out_pos; kind = inflate_block_header(st, m.t, m.lens, soff, slen); }
+        {   // the block header: lane 0 reads the bits, the wave builds the tables (inflate_core.h: inflate_block_rest, in its pieces)
+            uint32_t v = 0, ok = 0;
+            if (lane == 0) { opos = st.out_pos; ok = inflate_block_type(st, v) ? 1u : 0u; }
+            v = __builtin_amdgcn_readfirstlane(v); ok = __builtin_amdgcn_readfirstlane(ok);
+            if (ok && (v == 0u || v == 3u)) {
+                if (lane == 0) kind = inflate_block_rest(st, nullptr, m.lens, v, soff, slen);
+            } else if (ok) {
+                uint32_t nlen = 288, ndist = 30, good = 1, max_len = 0;
+                if (v == 1u) {
+                    for (uint32_t i = lane; i < 288u; i += 64u) m.lens[i] = (uint8_t)static_lit_len(i);
+                    if (lane < 30u) m.lens[288u + lane] = 5;
+                } else {
+                    uint8_t* cl = reinterpret_cast<uint8_t*>(m.pos);          // (batch / pos are idle between blocks)
+                    if (lane == 0) good = inflate_dyn_begin(st, cl, nlen, ndist) ? 1u : 0u;
+                    good = __builtin_amdgcn_readfirstlane(good); nlen = __builtin_amdgcn_readfirstlane(nlen); ndist = __builtin_amdgcn_readfirstlane(ndist);
+                    if (good) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        // the code-length code reuses the distance-table slots (7-bit fast index fits in 8)
+                        if (wave_build_decode_table(cl, 19u, m.t.dist_fast, 7u, m.t.dist_count, m.t.dist_sym, max_len, nullptr, m.batch) != 0) {
+                            if (lane == 0) st.status = kInfDataError;
+                            good = 0;
+                        }
+                    }
+                    if (good) {
+                        uint32_t bp0 = 0;
+                        if (lane == 0) bp0 = st.br.bit_pos();
+                        bp0 = __builtin_amdgcn_readfirstlane(bp0);
+                        const uint32_t bp1 = wave_dyn_lengths(m.ring, bp0, nin * 8u, m.t.dist_fast, m.lens, nlen + ndist);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (lane == 0) {
+                            if (bp1 != 0xffffffffu && m.lens[256] != 0) st.br.seek_bit(bp1);
+                            else good = inflate_dyn_lengths(st, m.t, m.lens, nlen, ndist) ? 1u : 0u;    // the sequential function, for its exact verdict
+                        }
+                        good = __builtin_amdgcn_readfirstlane(good);
+                    }
+                }
+                if (good) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int lr = wave_build_decode_table(m.lens, nlen, m.t.lit_fast, kLitFastBits, m.t.lit_count, m.t.lit_sym, max_len, m.t.lit_walk, m.batch);
+                    if (v == 2u) { if (lane == 0) good = inflate_table_ok(st, lr, max_len, true) ? 1u : 0u; good = __builtin_amdgcn_readfirstlane(good); }
+                }
+                if (good) {
+                    const int dr = wave_build_decode_table(m.lens + nlen, ndist, m.t.dist_fast, kDistFastBits, m.t.dist_count, m.t.dist_sym, max_len, m.t.dist_walk, m.batch);
+                    if (v == 2u) { if (lane == 0) good = inflate_table_ok(st, dr, max_len, false) ? 1u : 0u; good = __builtin_amdgcn_readfirstlane(good); }
+                }
+                kind = good ? kBlkHuffman : kBlkStop;
+            }
+        }
         kind = __builtin_amdgcn_readfirstlane(kind);
         if (kind == kBlkStop) break;
         if (kind == kBlkStored) {
@@ -1772,6 +1931,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             bp = __builtin_amdgcn_readfirstlane(bp); opos_u = __builtin_amdgcn_readfirstlane(opos_u);
             const uint32_t total_bits = nin * 8u;
             uint32_t block_done = 0, stop_status = kInfRunning;
+            ZWZ_ISTAMP(0);                                                    // block header, tables
             while (!block_done) {
                 top_up(bp >> 3);
                 // A round looks at up to kWinParts windows of 256 bits one after the other -- decode, follow the orbit, hand the
@@ -1830,6 +1990,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 // place, and the vector unit became what the kernel runs out of.)  Ranks and output positions come from ballots
                 // and DPP scans, and one pass of lane-parallel tests finds where the batch ends (64 symbols, end of block, an
                 // error, a code for the sequential decoder).
+                ZWZ_ISTAMP(1);                                                // refill + the window's 256 decodes
                 uint32_t jr[kWinSlots];
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
@@ -1860,6 +2021,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                         m.sym[rank] = make_uint2(val[r] | (inf[r] & 7u) << 25, (wb + r * 64u + lane) | (inf[r] >> 3) << 10);   // value < 2^25: length < 512, distance <= 32768
                     nsym += (uint32_t)__popcll(M[r]);
                 }
+                ZWZ_ISTAMP(2);                                                // the orbit, symbols to the batch
                 if (at >= kOrbitEnd || nsym > kBatch) break;                  // the orbit has stopped, or the batch is full
               }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1909,6 +2071,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 // flight together (copying match by match cost one L2 round trip per match: ~9 ms a chunk).
                 // The batch goes through the wave's LDS arrays (a ds_bpermute-based lookup returned wrong
                 // owners here; indexed LDS reads are also cheaper than eight bpermutes).
+                ZWZ_ISTAMP(3);                                                // one pass over the batch: positions, where it ends
                 const uint32_t bstart = opos_u;
                 const uint32_t bbytes = opos_new - bstart;
                 opos_u = opos_new;
@@ -1930,6 +2093,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
+                ZWZ_ISTAMP(4);                                                // the owner map
                 auto owner = [&](uint32_t pos, uint32_t& ov, uint32_t& op) {      // symbol of the batch that writes byte `pos`
                     uint32_t lo = 0;
                     if (mapped) lo = (uint32_t)m.ownb[pos - bstart] - 1u;
@@ -1973,6 +2137,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     if (in) dst[pos] = lit ? (uint8_t)ov : __hip_atomic_load(&dst[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     (void)need_fence;
                 }
+                ZWZ_ISTAMP(5);                                                // the bytes
                 if (stop == kEob) block_done = 1;
                 else if (stop == kSlow) {
                     // one symbol through the sequential decoder (long code, or its exact failure mode)
@@ -2019,6 +2184,10 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
         if (__builtin_amdgcn_readfirstlane(fin)) break;
     }
     if (lane == 0) { out_len[chunk] = st.out_pos; status[chunk] = st.status; }
+#if ZWZ_INF_EXP & 16
+    ZWZ_ISTAMP(6);                                                            // stored blocks, the sequential decoder, the rest
+    if (lane == 0) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&g_inf_times[ph], (unsigned long long)(iacc_[ph] >> 8));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2320,6 +2489,15 @@ hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
     if (a.order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(1024), 0, s, a.in_off, a.in_len, a.n, a.order);
     hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
                        a.out_stride, a.out_len, a.status, (const uint4*)a.order);
+#if ZWZ_INF_EXP & 16
+    if (getenv("ZWZ_INF_TIMES")) {
+        unsigned long long h[8], z[8] = {0};
+        ZWZ_TRY(hipStreamSynchronize(s));
+        ZWZ_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inf_times), sizeof h));
+        ZWZ_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_inf_times), z, sizeof z));
+        fprintf(stderr, "ZWZ_INF_TIMES n=%u header=%llu decode=%llu orbit=%llu symbols=%llu owners=%llu copy=%llu other=%llu\n", a.n, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+    }
+#endif
     return hipGetLastError();
 }
 
