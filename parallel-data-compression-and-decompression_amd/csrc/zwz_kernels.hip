@@ -2001,10 +2001,16 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
                     uint64_t mk = 0;
-                    while (at < wb + 64u * (r + 1u)) {                        // (at >= wb + 64 r: offsets only grow)
-                        const uint32_t l = at - wb - 64u * r;
-                        mk |= 1ull << l;
-                        at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l);
+                    const uint32_t lim = wb + 64u * (r + 1u);
+                    auto hop = [&] { const uint32_t l = at - wb - 64u * r; mk |= 1ull << l; at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l); };
+                    while (at < lim) {                                        // (at >= wb + 64 r: offsets only grow)
+                        hop();                                                // four hops a trip by hand (the optimizer does not unroll around a
+                        if (at >= lim) break;                                 // v_readlane): three of four loop branches fall through instead of
+                        hop();                                                // being taken
+                        if (at >= lim) break;
+                        hop();
+                        if (at >= lim) break;
+                        hop();
                     }
                     M[r] = mk;
                 }
