@@ -1416,6 +1416,17 @@ __global__ __launch_bounds__(kEncStoredThreads) void encode_stored_kernel(const 
                                            reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride), out_len + chunk);
 }
 
+// (ZWZ_ENC_EXP & 16, experiment builds only -- tools/encode_times.sh: wave 0 of every workgroup sums the cycles per phase in registers,
+// adds them, >> 8, to g_enc_times[] at its end; launch_deflate prints them when ZWZ_ENC_TIMES is set)
+#ifndef ZWZ_ENC_EXP
+#define ZWZ_ENC_EXP 0
+#endif
+#if ZWZ_ENC_EXP & 16
+__device__ unsigned long long g_enc_times[8];
+#define ZWZ_ESTAMP(ph) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); eacc_[(ph)] += (uint32_t)(now_ - estamp_); estamp_ = now_; } while (0)
+#else
+#define ZWZ_ESTAMP(ph) do { } while (0)
+#endif
 __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
@@ -1440,6 +1451,10 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     __shared__ uint32_t s_item;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = tickets[kTicketHuffCount];       // final: encode_stored_kernel has finished
+#if ZWZ_ENC_EXP & 16
+    uint64_t estamp_ = __builtin_amdgcn_s_memtime();
+    uint32_t eacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
     if (tid == 0) s_item = atomicAdd(&tickets[kTicketHuffNext], 1u);
     __syncthreads();
@@ -1503,6 +1518,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         s_total_bytes = (uint32_t)(bit >> 3) + 4;    // + Adler-32
     }
     __syncthreads();
+    ZWZ_ESTAMP(0);                                            // ticket, masks, match ranks, codes, the stream's layout (thread 0)
     {   // the staging buffer, zeroed as far as this chunk's stream reaches (a whole 64 KiB per chunk was most of what a
         // 4-byte chunk cost: the 10 000 tail chunks of BASELINE configs[1] took 0.2 ms)
         const uint32_t nz = min(kOutWords, (s_total_bytes + 3u) / 4u + 2u);
@@ -1529,6 +1545,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         }
     }
 
+    ZWZ_ESTAMP(1);                                            // staging zeroed, block headers
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
     uint8_t* s_out8 = reinterpret_cast<uint8_t*>(s_out);
     {
@@ -1613,6 +1630,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             if (p_n) work(p_ent, p_byte, p_rec, lane < p_n);
         };
 
+        ZWZ_ESTAMP(2);                                        // Adler partials, stored blocks' bytes
         uint32_t mine = 0;
         for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
             if (live) {
@@ -1622,7 +1640,9 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         });
         for (uint32_t d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
         if (lane == 0) s_wsum[wave] = mine;
+        ZWZ_ESTAMP(3);                                        // first pass: code lengths
         __syncthreads();
+        ZWZ_ESTAMP(4);                                        // waiting for the other waves
         uint32_t running = 0;      // symbol bits emitted before this wave's segment (all Huffman blocks)
         for (uint32_t i = 0; i < wave; i++) running += s_wsum[i];
         for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
@@ -1641,6 +1661,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         });
     }
 
+    ZWZ_ESTAMP(5);                                            // second pass: bits into the staging buffer
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
     for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
     if (lane_id() == 0) { s_adler_a[tid >> 6] = a_sum; s_adler_b[tid >> 6] = b_sum; }
@@ -1656,9 +1677,14 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     __syncthreads();
     const uint32_t n_out = s_total_bytes < kChunk ? s_total_bytes : kChunk;
     uint32_t* gout = reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride);
+    ZWZ_ESTAMP(6);                                            // waiting for the other waves, the checksum
     for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
     __syncthreads();                                          // everyone has read s_item, s_total_bytes and s_out
+    ZWZ_ESTAMP(7);                                            // the stream out
   }
+#if ZWZ_ENC_EXP & 16
+    if (tid == 0) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&g_enc_times[ph], (unsigned long long)(eacc_[ph] >> 8));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2362,6 +2388,15 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
         hipLaunchKernelGGL(encode_kernel, dim3(a.n < slots ? a.n : slots), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
                            a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links, huff_list, a.tickets);
     }
+#if ZWZ_ENC_EXP & 16
+    if (getenv("ZWZ_ENC_TIMES")) {
+        unsigned long long h[8], z[8] = {0};
+        ZWZ_TRY(hipStreamSynchronize(s));
+        ZWZ_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_enc_times), sizeof h));
+        ZWZ_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_times), z, sizeof z));
+        fprintf(stderr, "ZWZ_ENC_TIMES n=%u setup=%llu zero_hdr=%llu adler=%llu pass1=%llu wait1=%llu pass2=%llu wait2=%llu out=%llu\n", a.n, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
+#endif
     if (ev) ZWZ_TRY(hipEventRecord(ev[6], s));
     return hipGetLastError();
 }

@@ -326,6 +326,29 @@ def test_inflate_corrupt_streams_stop_like_oracle(codec, oracle):
             assert g == w
 
 
+def test_inflate_damaged_dynamic_headers_stop_like_oracle(codec, oracle):
+    """The block header is read by the whole wave (tables by ordered LDS adds, the code-length symbols window-parallel) with the
+    sequential function as the way out for anything out of the ordinary.  Every such way out, on purpose: a dynamic block's stream
+    cut at every byte of its header and a little beyond, and with every single bit of the header flipped (lengths that no longer
+    add up, a repeat with nothing before it, runs past HLIT + HDIST, over-subscribed and incomplete codes, a missing
+    end-of-block code ...).  What comes out must be what the oracle's decoder gives for the same bytes."""
+    import zlib
+    payloads = []
+    for kind, seed, n in (("text", 1, 3000), ("skewed", 2, 900), ("text", 3, 40000)):
+        data = corpus.make(kind, 9100 + seed, n)
+        z = zlib.compress(data, 6)
+        assert (z[2] >> 1) & 3 == 2                                  # a dynamic block first
+        hdr_bytes = 120
+        payloads += [z[:k] for k in range(2, hdr_bytes + 40)]
+        for bit in range(16, 8 * hdr_bytes):
+            b = bytearray(z); b[bit >> 3] ^= 1 << (bit & 7); payloads.append(bytes(b))
+    got, status = codec.inflate_chunks(payloads)
+    for i, (p, g) in enumerate(zip(payloads, got)):
+        w, total, st = oracle.inflate(p, 1 << 20)
+        if total <= CHUNK:
+            assert g == w, (i, len(p))
+
+
 def test_roundtrip_property_full_size(codec):
     # size-independent property at batch scale: text-like data round-trips exactly; incompressible
     # full chunks come back 22 bytes short, exactly like the reference
