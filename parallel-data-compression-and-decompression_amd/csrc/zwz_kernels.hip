@@ -940,6 +940,16 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 //   4. a position is covered by a match iff the latest event at or before it is an interior start
 //      (events: interior starts and fresh positions); symbols = the rest.
 // (A scalar walk cost ~150 vector instructions per symbol: 81 ms for 50k text chunks.)
+// (ZWZ_PARSE_EXP & 16, experiment builds only -- tools/parse_times.sh: every wave sums the cycles per phase in registers)
+#ifndef ZWZ_PARSE_EXP
+#define ZWZ_PARSE_EXP 0
+#endif
+#if ZWZ_PARSE_EXP & 16
+__device__ unsigned long long g_parse_times[8];
+#define ZWZ_PSTAMP(ph) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pacc_[(ph)] += (uint32_t)(now_ - pstamp_); pstamp_ = now_; } while (0)
+#else
+#define ZWZ_PSTAMP(ph) do { } while (0)
+#endif
 struct ParseWaveMem {
     uint2 win[128];            // records of positions & 127 (this block and the next)
     uint32_t ring_r[16], ring_s[16], ring_m[16], ring_m32[16];   // 8 x 64-bit words each, as halves
@@ -984,6 +994,10 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         if (w < nwords) { hw_pre = hm_word(w); if ((hw_pre >> lane) & 1ull) e = ent[(w << 6) + lane]; }
         return e;
     };
+    // (A second block of lookahead -- records asked for two blocks before they go into the window -- changes nothing as long as
+    // the compiler's wait in front of the window write is vmcnt(0): it waits for the younger request as well.  The wait for the
+    // records is 21 % of the kernel on text and 46 % on 7 KB chunks, ZWZ_PARSE_EXP; counted waits would need every block to issue
+    // the same number of loads and stores.)
     uint2 pre = fetch(0);
     m.win[lane] = pre;
     uint64_t hw_cur = hw_pre;                        // has128 word of the block being processed
@@ -993,8 +1007,13 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
     uint32_t n_match = 0;                            // wave-uniform
     auto lookup = [&](uint32_t p, uint32_t sel) -> uint32_t { const uint2 e = m.win[p & 127u]; return sel ? e.y : e.x; };
 
+#if ZWZ_PARSE_EXP & 16
+    uint64_t pstamp_ = __builtin_amdgcn_s_memtime();
+    uint32_t pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (uint32_t blk = 0; blk < nwords; blk++) {
         const uint32_t base = blk << 6, q = base + lane;
+        ZWZ_PSTAMP(5);                                   // the tail of the block before: outputs, ring reset
         {   // run of literal-only blocks entered at a block start with nothing pending: settle up to 64
             // blocks at once (incompressible data is almost all such runs)
             const uint32_t slot = 2 * (blk & 7u);
@@ -1043,8 +1062,10 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         }
         m.flag[lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        ZWZ_PSTAMP(0);                                   // quiet-block tests, the window's next records (fetch issued, previous written to LDS)
         FreshStep st{q + 1, q, 0u, 1u};
         if (valid) st = fresh_step(lookup, q, L);
+        ZWZ_PSTAMP(1);                                   // every lane's step
         uint32_t succ = st.next >= base + 64u ? 64u : st.next - base;      // 64 = leaves the block
         const uint64_t entry = ((uint64_t)m.ring_r[2 * (blk & 7u)] | ((uint64_t)m.ring_r[2 * (blk & 7u) + 1] << 32));
         const uint64_t validm = __ballot(valid);
@@ -1067,6 +1088,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
                 marks &= validm;
             }
         }
+        ZWZ_PSTAMP(2);                                   // the orbit of the block's entry
         const bool fresh = (marks >> lane) & 1ull;
         if (fresh) {
             const uint32_t nx = st.next;
@@ -1080,6 +1102,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         }
         last_is_match |= (uint32_t)(__ballot(fresh && !st.is_lit && st.next == L) != 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        ZWZ_PSTAMP(3);                                   // events into the rings
         const uint32_t slot = 2 * (blk & 7u);
         const uint64_t S = (uint64_t)m.ring_s[slot] | ((uint64_t)m.ring_s[slot + 1] << 32);
         const uint64_t M = (uint64_t)m.ring_m[slot] | ((uint64_t)m.ring_m[slot + 1] << 32);
@@ -1092,6 +1115,7 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         const uint64_t sym_w = ~cover & validm;
         n_sym += (uint32_t)__popcll(sym_w);
         if (lane == 0) { gsym[blk] = sym_w; gmst[blk] = M; }
+        ZWZ_PSTAMP(4);                                   // cover, symbol word
         if (M) {                                     // this block's match starts are final: their records go out, selected and compact
             if ((M >> lane) & 1ull) {
                 const uint2 e = m.win[q & 127u];
@@ -1110,6 +1134,9 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
         ci.n_blocks = s_in / kSymsPerBlock + 1;
         info[chunk] = ci;
     }
+#if ZWZ_PARSE_EXP & 16
+    if (lane == 0) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&g_parse_times[ph], (unsigned long long)(pacc_[ph] >> 8));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2374,6 +2401,15 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links);
+#if ZWZ_PARSE_EXP & 16
+    if (getenv("ZWZ_PARSE_TIMES")) {
+        unsigned long long h[8], z[8] = {0};
+        ZWZ_TRY(hipStreamSynchronize(s));
+        ZWZ_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_parse_times), sizeof h));
+        ZWZ_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_parse_times), z, sizeof z));
+        fprintf(stderr, "ZWZ_PARSE_TIMES n=%u fetch=%llu steps=%llu orbit=%llu events=%llu cover=%llu out=%llu\n", a.n, h[0], h[1], h[2], h[3], h[4], h[5]);
+    }
+#endif
     if (ev) ZWZ_TRY(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(blockify_kernel, dim3(a.n), dim3(kBlockifyThreads), 0, s, a.in, a.in_off, a.in_len, a.entries, a.sym, a.mst,
                        a.info, a.blocks, a.links);
