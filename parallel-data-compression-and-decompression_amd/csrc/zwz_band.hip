@@ -159,6 +159,10 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
                         h[j] = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
                         if (16u * i + j < n) atomicAdd(&tab[h[j] >> 1], (h[j] & 1u) ? 0x10000u : 1u);
                     }
+                    // (what goes out is the counter's place as the ranking wave wants it: byte offset of the dword | which half -- a lone
+                    // wave pays ~7 cycles an instruction, and this is done here by four)
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; j++) h[j] = (h[j] >> 1) << 2 | (h[j] & 1u);
                     uint4* hb4 = reinterpret_cast<uint4*>(hb + 16u * i);
                     hb4[0] = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
                     hb4[1] = make_uint4(h[8] | h[9] << 16, h[10] | h[11] << 16, h[12] | h[13] << 16, h[14] | h[15] << 16);
@@ -191,35 +195,41 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
             // Whole trips of eight steps run without a single test (every lane has a position: guarded per lane, the loop was
             // mostly exec-mask bookkeeping); the next trip's hashes are on their way while this one ranks.
             const uint32_t full = n >> 9;                                       // trips of 512 positions
+            // (running pointers, so that a trip's eight loads and eight stores are one address and constant offsets; hb holds byte
+            // offset | half, see the histogram: per step the wave is left with and + two shifts + the add, and a shift + the store)
+            auto bump = [&](uint32_t w) { return atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(tab) + (w & 0xfffcu)), 1u << ((w & 1u) << 4)); };
+            const uint16_t* hin = hb + lane;
+            uint16_t* o = out + lane;
             uint32_t hv[8];
-            auto ask = [&](uint32_t t, uint32_t* h8) {
+            auto ask = [&](uint32_t* h8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) h8[j] = hb[(t * 8u + j) * 64u + lane];
+                for (uint32_t j = 0; j < 8; j++) h8[j] = hin[j * 64u];
+                hin += 512;
             };
-            if (full) ask(0u, hv);
-            uint32_t hp[8], op[8];                                              // the previous trip's hashes and what its adds returned
+            if (full) ask(hv);
+            uint32_t hp[8], op[8];                                              // the previous trip's entries and what its adds returned
             for (uint32_t t = 0; t < full; t++) {
                 uint32_t hn[8], old[8];
-                if (t + 1u < full) ask(t + 1u, hn);
+                if (t + 1u < full) ask(hn);
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) old[j] = atomicAdd(&tab[hv[j] >> 1], 1u << ((hv[j] & 1u) << 4));
+                for (uint32_t j = 0; j < 8; j++) old[j] = bump(hv[j]);
                 // (the previous trip's results are written out while this trip's adds are on their way through the LDS)
                 if (t) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) out[((t - 1u) * 8u + j) * 64u + lane] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                    for (uint32_t j = 0; j < 8; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                    o += 512;
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) { hp[j] = hv[j]; op[j] = old[j]; hv[j] = hn[j]; }
             }
             if (full) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) out[((full - 1u) * 8u + j) * 64u + lane] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                for (uint32_t j = 0; j < 8; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
             }
             for (uint32_t p = full * 512u + lane; p - lane < n; p += 64u) {     // the ragged end, a step at a time
                 if (p < n) {
-                    const uint32_t h = hb[p];
-                    const uint32_t old = atomicAdd(&tab[h >> 1], 1u << ((h & 1u) << 4));
-                    out[p] = (uint16_t)(old >> ((h & 1u) << 4));
+                    const uint32_t w = hb[p];
+                    out[p] = (uint16_t)(bump(w) >> ((w & 1u) << 4));
                 }
             }
         }
