@@ -49,7 +49,7 @@ typedef enum zwz_status {
     ZWZ_OK = 0,
     ZWZ_E_INVALID = -1,   /* bad argument (null pointer, misaligned device slot, size > 65535) */
     ZWZ_E_HIP = -2,       /* a HIP runtime call failed; zwz_last_error() has the text */
-    ZWZ_E_NO_DEVICE = -3, /* no usable gfx950 device (none visible, or it fails zwz_ctx_create's check of the LDS exchange order lz_links needs) */
+    ZWZ_E_NO_DEVICE = -3, /* no usable gfx950 device (none visible, or it fails every one of zwz_ctx_create's self-tests: see zwz_ctx_set_option) */
     ZWZ_E_IO = -4,        /* file system error */
     ZWZ_E_NOMEM = -5,
     ZWZ_E_FORMAT = -6     /* malformed .zwz shard */
@@ -146,6 +146,16 @@ int zwz_decompress_dir_ranked(zwz_ctx *ctx, const char *src_dir, const char *dst
  * nothing is truncated and every file round-trips with a matching MD5; the container is unchanged and the reference's
  * decoder reads such shards.  The environment variables ZWZ_LOSSLESS=1 / ZWZ_CHUNK_SIZE=<n> do the same for the CLI. */
 int zwz_ctx_set_chunk_size(zwz_ctx *ctx, uint32_t bytes);
+
+/* Test and diagnosis switches of one context; no reference counterpart (the reference's zlib has one code path,
+ * compression.cpp:119-134 / decompression.cpp:16-36) and no effect on any byte produced -- they choose between kernels that compute
+ * the same thing, so that tests can drive each of them and a device that fails a self-test at zwz_ctx_create still gets a codec:
+ *   "match"           "auto" (default: per chunk, by a sample of its trigrams) | "walk" (chain links + walk) | "band" (sort + banded search)
+ *   "plan"            "wave" (default) | "serial"   block flush: a lane per heap + a wave per block, or all of it on one lane
+ *   "inflate_header"  "wave" (default) | "serial"   a block's decoding tables by the whole wave, or by lane 0
+ * Defaults come from ZWZ_MATCH / ZWZ_PLAN / ZWZ_INFLATE_HEADER, read once in zwz_ctx_create (never per launch).  ZWZ_E_INVALID for
+ * an unknown name or value. */
+int zwz_ctx_set_option(zwz_ctx *ctx, const char *name, const char *value);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,8 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ct
                                 ctypes.c_uint32)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzwz_hip.so")
+# (ZWZ_LIB: another build of the same library -- tools/gpu.sh's instrumented libzwz_hip_exp.so; such a build announces itself on stderr)
+LIB_PATH = os.environ.get("ZWZ_LIB") or os.path.join(_HERE, "libzwz_hip.so")
 _lib = None
 
 
@@ -73,6 +74,7 @@ def lib():
         L.zwz_decompress_dir.argtypes = [vp, c.c_char_p, c.c_char_p, c.POINTER(c.c_int)]
         L.zwz_decompress_dir_ranked.argtypes = [vp, c.c_char_p, c.c_char_p, c.c_int, c.c_int, ALLGATHER_FN, vp, c.POINTER(c.c_int)]
         L.zwz_ctx_set_chunk_size.argtypes = [vp, u32]
+        L.zwz_ctx_set_option.argtypes = [vp, c.c_char_p, c.c_char_p]
         _lib = L
     return _lib
 
@@ -217,6 +219,11 @@ class Codec:
                                              cb, None, ctypes.byref(bad))
         _check(rc, "zwz_decompress_dir", md5_mismatches=bad.value)
         return bad.value
+
+    def set_option(self, name, value):
+        """Test / experiment switches of this context (include/zwz.h: zwz_ctx_set_option): "match" = auto | walk | band,
+        "plan" = wave | serial, "inflate_header" = wave | serial.  Every choice produces the same bytes."""
+        _check(lib().zwz_ctx_set_option(self._h, name.encode(), value.encode()), "zwz_ctx_set_option")
 
     def set_chunk_size(self, nbytes):
         """Raw bytes per Chunk for do_compression (0 = the reference's 65535).  Opt-in, not bit-exact with the reference's

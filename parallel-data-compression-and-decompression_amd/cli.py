@@ -151,7 +151,8 @@ def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=
                 failure = e
             if gather and world > 1:
                 path = os.path.join(shard_dir, "compressed_%d.zwz" % rank)
-                blob = open(path, "rb").read() if os.path.exists(path) else b""
+                # (a rank that failed hands over nothing -- a partially written shard must not reach <dst> under a good name; csrc/main.cpp does the same)
+                blob = open(path, "rb").read() if failure is None and os.path.exists(path) else b""
                 blobs = gather_blobs(blob, 0)
                 if rank == 0:
                     for r, b in enumerate(blobs):

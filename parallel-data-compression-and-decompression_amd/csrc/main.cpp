@@ -268,30 +268,64 @@ struct Rccl {
             return hipMemcpy(send, mine, one, hipMemcpyHostToDevice) == hipSuccess && ncclAllGather(send, d, count, ncclUint64, comm, stream) == ncclSuccess &&
                    hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(all, d, one * (size_t)world, hipMemcpyDeviceToHost) == hipSuccess; }) ? 0 : -1;
     }
-    // "a final gather of per-shard .zwz blobs" (north star; the reference leaves every rank's shard where the rank wrote it): sizes by
-    // all-gather, then one grouped send per rank and the matching receives on rank 0.  blobs[r] is filled on rank 0 only.
-    bool gather_blobs(const std::string& mine, std::vector<std::string>& blobs) {
+    // "a final gather of per-shard .zwz blobs" (north star; the reference leaves every rank's shard where the rank wrote it).  Sizes by
+    // all-gather; then every rank's shard travels to rank 0 in pieces of at most kPiece bytes through ONE staging buffer per rank --
+    // device memory does not grow with shard size x ranks (round 3 allocated every peer's whole shard on rank 0 at once) -- and every
+    // send has exactly one matching receive: whether the transfers happen at all is decided by an all-gather of "my staging
+    // buffer exists", so either every rank enters them or none does (an unmatched ncclSend never completes and RCCL has no
+    // time-out).  Rank 0 writes each shard to <out_dir>/compressed_<r>.zwz through a temporary name.  my_path: this rank's shard
+    // file ("" or unreadable: the rank contributes nothing, e.g. because it failed or had no file to compress).
+    static constexpr size_t kPiece = (size_t)64 << 20;
+    bool gather_files(const std::string& my_path, const std::string& out_dir) {
+        FILE* f = rank != 0 && !my_path.empty() ? fopen(my_path.c_str(), "rb") : nullptr;
+        uint64_t my_size = 0;
+        if (f) { struct stat st {}; if (fstat(fileno(f), &st) == 0) my_size = (uint64_t)st.st_size; }
         std::vector<uint64_t> sizes((size_t)world);
-        const uint64_t my_size = mine.size();
-        if (allgather(&my_size, sizes.data(), 1) != 0) return false;
-        std::vector<void*> bufs((size_t)world, nullptr);
-        bool ok = true;
-        auto free_all = [&] { for (void* p : bufs) if (p) (void)hipFree(p); };
-        if (rank == 0) { for (int r = 1; r < world && ok; r++) if (sizes[(size_t)r]) ok = hipMalloc(&bufs[(size_t)r], (size_t)sizes[(size_t)r]) == hipSuccess; }
-        else if (my_size) ok = hipMalloc(&bufs[(size_t)rank], (size_t)my_size) == hipSuccess && hipMemcpy(bufs[(size_t)rank], mine.data(), (size_t)my_size, hipMemcpyHostToDevice) == hipSuccess;
-        // (a rank that could not allocate still enters the group with what it has: the peers' sends and receives must pair up or fail together)
-        if (ncclGroupStart() != ncclSuccess) { free_all(); return false; }
-        if (rank == 0) { for (int r = 1; r < world; r++) if (sizes[(size_t)r] && bufs[(size_t)r]) ok = ncclRecv(bufs[(size_t)r], (size_t)sizes[(size_t)r], ncclChar, r, comm, stream) == ncclSuccess && ok; }
-        else if (my_size && bufs[(size_t)rank]) ok = ncclSend(bufs[(size_t)rank], (size_t)my_size, ncclChar, 0, comm, stream) == ncclSuccess && ok;
-        ok = ncclGroupEnd() == ncclSuccess && ok;
-        ok = hipStreamSynchronize(stream) == hipSuccess && ok;
-        blobs.assign((size_t)world, std::string());
-        if (rank == 0) {
-            blobs[0] = mine;
-            for (int r = 1; r < world && ok; r++) if (sizes[(size_t)r]) { blobs[(size_t)r].resize((size_t)sizes[(size_t)r]); ok = hipMemcpy(&blobs[(size_t)r][0], bufs[(size_t)r], (size_t)sizes[(size_t)r], hipMemcpyDeviceToHost) == hipSuccess; }
+        bool ok = allgather(&my_size, sizes.data(), 1) == 0;
+        uint64_t biggest = 0;
+        for (int r = 1; r < world; r++) biggest = std::max(biggest, sizes[(size_t)r]);
+        const size_t piece = (size_t)std::min<uint64_t>(biggest, kPiece);
+        void* d = nullptr; void* h = nullptr;
+        const bool need = ok && piece && (rank == 0 || my_size);
+        uint64_t ready = !ok ? 0 : !need ? 1 : (hipMalloc(&d, piece) == hipSuccess && hipHostMalloc(&h, piece, hipHostMallocDefault) == hipSuccess);
+        std::vector<uint64_t> all_ready((size_t)world, 0);
+        if (ok) ok = allgather(&ready, all_ready.data(), 1) == 0;                     // (a rank whose first all-gather failed cannot be helped: the communicator is gone)
+        for (int r = 0; r < world && ok; r++) if (!all_ready[(size_t)r]) { ok = false; if (rank == 0) fprintf(stderr, "rank 0: rank %d has no staging memory for the shard gather\n", r); }
+        if (ok && piece) {
+            for (int r = 1; r < world && ok; r++) {
+                const uint64_t total = sizes[(size_t)r];
+                if (!total || (rank != 0 && rank != r)) continue;
+                FILE* out = nullptr;
+                const std::string final_path = out_dir + "/compressed_" + std::to_string(r) + ".zwz", tmp_path = final_path + ".part";
+                if (rank == 0 && !(out = fopen(tmp_path.c_str(), "wb"))) fprintf(stderr, "rank 0: cannot create %s\n", tmp_path.c_str());
+                bool io_ok = rank != 0 || out != nullptr;
+                // (an I/O failure on either side does not stop the pieces: the peer is already committed to them; it marks the shard bad)
+                for (uint64_t off = 0; off < total; off += piece) {
+                    const size_t k = (size_t)std::min<uint64_t>(piece, total - off);
+                    if (rank == r) {
+                        if (io_ok && fread(h, 1, k, f) != k) io_ok = false;
+                        ok = hipMemcpyAsync(d, h, k, hipMemcpyHostToDevice, stream) == hipSuccess && ncclSend(d, k, ncclChar, 0, comm, stream) == ncclSuccess &&
+                             hipStreamSynchronize(stream) == hipSuccess && ok;
+                    } else {
+                        ok = ncclRecv(d, k, ncclChar, r, comm, stream) == ncclSuccess && hipMemcpyAsync(h, d, k, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                             hipStreamSynchronize(stream) == hipSuccess && ok;
+                        if (ok && io_ok && fwrite(h, 1, k, out) != k) io_ok = false;
+                    }
+                    if (!ok) break;          // the communicator itself failed: nothing further can be matched
+                }
+                if (out) { if (fclose(out) != 0) io_ok = false; if (ok && io_ok) io_ok = rename(tmp_path.c_str(), final_path.c_str()) == 0; else unlink(tmp_path.c_str()); }
+                if (!io_ok) { fprintf(stderr, "rank %d: I/O error while %s shard %d\n", rank, rank == 0 ? "writing" : "reading", r); ok = false; }
+            }
         }
-        free_all();
-        return ok;
+        if (f) fclose(f);
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        // every rank learns whether every transfer and every write succeeded (a sender must not delete a shard rank 0 could not store)
+        uint64_t fine = ok ? 1 : 0;
+        std::vector<uint64_t> all_fine((size_t)world, 0);
+        if (allgather(&fine, all_fine.data(), 1) != 0) return false;
+        for (int r = 0; r < world; r++) if (!all_fine[(size_t)r]) return false;
+        return true;
     }
     int worst_status(int rc) {                                      // barrier + every rank learns whether any rank failed
         int64_t v = rc != 0;
@@ -435,17 +469,16 @@ int main(int argc, char* argv[]) {
             if (world_rank < zwz_count_non_empty_lines(record)) rc = zwz_compress_dir(ctx, source_path.c_str(), shard_dir.c_str(), record, world_rank, world_size);
             else printf("Rank: %d - No file to compress\n", world_rank);
         }
-        if (gather) {       // every rank of the communicator, whatever its own status (a failed rank contributes an empty shard)
+        if (gather) {       // every rank of the communicator, whatever its own status (a failed or idle rank contributes nothing)
             const std::string mine_path = shard_dir + "/compressed_" + std::to_string(world_rank) + ".zwz";
-            std::string mine;
-            if (rc == ZWZ_OK && world_rank != 0) (void)read_all(mine_path, mine);
-            std::vector<std::string> blobs;
-            if (!nc.gather_blobs(mine, blobs)) { fprintf(stderr, "rank %d: RCCL gather of the shards failed\n", world_rank); if (rc == ZWZ_OK) rc = ZWZ_E_IO; }
-            else if (world_rank == 0)
-                for (int r = 1; r < world_size; r++)
-                    if (!blobs[(size_t)r].empty() && !write_atomic(output_path + "/compressed_" + std::to_string(r) + ".zwz", blobs[(size_t)r])) { fprintf(stderr, "rank 0: cannot write rank %d's shard\n", r); if (rc == ZWZ_OK) rc = ZWZ_E_IO; }
-            if (trace) fprintf(stderr, "zwz: rank %d: shards gathered over RCCL\n", world_rank);
-            if (world_rank != 0 && shard_dir != output_path) { unlink(mine_path.c_str()); rmdir(shard_dir.c_str()); }
+            const bool gathered = nc.gather_files(rc == ZWZ_OK && world_rank != 0 ? mine_path : std::string(), output_path);
+            if (trace) fprintf(stderr, "zwz: rank %d: shard gather over RCCL %s\n", world_rank, gathered ? "done" : "FAILED");
+            if (!gathered) {
+                // the shard stays where the rank wrote it: nothing is lost, and the message says where it is
+                if (world_rank != 0 && rc == ZWZ_OK) fprintf(stderr, "rank %d: RCCL gather of the shards failed; this rank's shard is kept at %s\n", world_rank, mine_path.c_str());
+                else fprintf(stderr, "rank %d: RCCL gather of the shards failed\n", world_rank);
+                if (rc == ZWZ_OK) rc = ZWZ_E_IO;
+            } else if (world_rank != 0 && shard_dir != output_path) { unlink(mine_path.c_str()); rmdir(shard_dir.c_str()); }
         }
         if (!private_list.empty()) unlink(private_list.c_str());
     } else {

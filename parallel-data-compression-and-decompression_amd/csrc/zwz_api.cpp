@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace zwz {
@@ -38,7 +39,10 @@ namespace {
 // assembly: a toolchain change could break either without a diagnostic, and wrong links mean shards that are no longer
 // the reference's.  Three chunks -- text-like with long chains, incompressible, a ragged short one -- go through the
 // kernel and every link is compared with zlib's insert restated on the host (prev[p] = head[h]; head[h] = p).
-int links_self_test(zwz_ctx* c) {
+// Returns ZWZ_OK with *bad = 0, or bit 0 set (lz_links' links are wrong) / bit 1 set (lz_sort's order is wrong) and the text of the
+// first finding in zwz_last_error(); a HIP failure is returned as such.
+int links_self_test(zwz_ctx* c, uint32_t* bad) {
+    *bad = 0;
     // three workgroups for eight chunks: each one runs on from chunk to chunk (full, short, one-block, empty and tiny ones)
     constexpr uint32_t K = 8;
     const uint32_t lens[K] = {65535u, 40000u, 0u, 2049u + 37u, 5u, 6144u, 65535u, 2u};
@@ -100,15 +104,16 @@ int links_self_test(zwz_ctx* c) {
             head[h] = (uint16_t)p;
             linked += want != 0;
             if (got[(size_t)k * kLinkStride + p] != want) {
-                set_error("zwz_ctx_create: lz_links self-test failed (chunk %u, position %u: link %u, expected %u) -- the kernel's hand-scheduled "
-                          "code does not survive this toolchain", k, p, (unsigned)got[(size_t)k * kLinkStride + p], (unsigned)want);
-                return ZWZ_E_NO_DEVICE;
+                if (!(*bad & 1u)) set_error("zwz_ctx_create: lz_links self-test failed (chunk %u, position %u: link %u, expected %u) -- the kernel's hand-scheduled "
+                                            "code does not survive this toolchain", k, p, (unsigned)got[(size_t)k * kLinkStride + p], (unsigned)want);
+                *bad |= 1u;
+                break;
             }
         }
         for (uint32_t p = lens[k] >= kMinMatch ? lens[k] - (kMinMatch - 1u) : 0u; p < lens[k]; p++) {   // the last positions have no trigram: NIL
-            if (got[(size_t)k * kLinkStride + p] != 0) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: a link behind the last trigram)", k); return ZWZ_E_NO_DEVICE; }
+            if (got[(size_t)k * kLinkStride + p] != 0 && !(*bad & 1u)) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: a link behind the last trigram)", k); *bad |= 1u; }
         }
-        if (stat[k] != linked) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: %u linked positions counted, %u expected)", k, stat[k], linked); return ZWZ_E_NO_DEVICE; }
+        if (stat[k] != linked && !(*bad & 1u)) { set_error("zwz_ctx_create: lz_links self-test failed (chunk %u: %u linked positions counted, %u expected)", k, stat[k], linked); *bad |= 1u; }
         // the sorted array: a stable counting sort of the positions by bucket
         const uint32_t n = lens[k] >= kMinMatch ? lens[k] - (kMinMatch - 1u) : 0u;
         std::vector<uint32_t> start(32769, 0);
@@ -118,11 +123,68 @@ int links_self_test(zwz_ctx* c) {
             const uint32_t h = hash3(d[p], d[p + 1], d[p + 2]), want = start[h]++;
             const uint32_t got_d = reinterpret_cast<const uint16_t*>(srt.data() + (size_t)k * kSortedStride)[p];
             if (got_d != want) {
-                set_error("zwz_ctx_create: lz_sort self-test failed (chunk %u, position %u: sorted index %u, expected %u) -- the returning LDS add does not "
-                          "serve same-address lanes in lane order on this device", k, p, got_d, want);
-                return ZWZ_E_NO_DEVICE;
+                if (!(*bad & 2u)) set_error("zwz_ctx_create: lz_sort self-test failed (chunk %u, position %u: sorted index %u, expected %u) -- the returning LDS add does not "
+                                            "serve same-address lanes in lane order on this device", k, p, got_d, want);
+                *bad |= 2u;
+                break;
             }
         }
+    }
+    return ZWZ_OK;
+}
+
+// Known-answer test of the two other users of the ordered LDS add: the wave form of the block flush (zwz_plan.hip:
+// next_code[len]++ in symbol order) and inflate's wave-built decoding tables (wave_build_decode_table: a symbol's place in sorted[] and
+// hence its code).  Three small chunks with dynamic-Huffman blocks -- text-like, a geometric byte distribution whose tree is deep, one
+// with long matches and far distances -- are deflated with the serial and the wave flush and inflated with serial and wave headers:
+// the serial forms must reproduce the input (else the device cannot run the codec at all), and a wave form that disagrees with its
+// serial form is switched off for this context.  A few milliseconds per context.
+int codec_self_test(zwz_ctx* c) {
+    constexpr uint32_t K = 3;
+    const uint32_t lens[K] = {24000u, 30000u, 40000u};
+    std::vector<uint8_t> in;
+    uint64_t offs[K];
+    uint32_t rng = 0x9e3779b9u;
+    auto next = [&] { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (uint32_t k = 0; k < K; k++) {
+        offs[k] = in.size();
+        const size_t base = in.size();
+        for (uint32_t i = 0; i < lens[k]; i++) {
+            uint8_t b;
+            if (k == 0) b = (next() & 15u) < 3 && i >= 9 ? in[base + i - 9 + (next() & 3u)] : (uint8_t)(97u + next() % 7u);
+            else if (k == 1) { uint32_t r = next() | 1u << 23, z = 0; while (!(r & 1u)) { r >>= 1; z++; } b = (uint8_t)(32u + z); }   // P(32 + z) = 2^-(z + 1): a tree as deep as its alphabet
+            else b = i >= 20000u && ((i / 37u) & 1u) ? in[base + i - 20000u] : (uint8_t)next();                                       // far copies in noise: long distance codes
+            in.push_back(b);
+        }
+    }
+    const uint32_t keep_plan = c->plan_serial, keep_hdr = c->inflate_serial_header;
+    std::vector<uint8_t> p_serial((size_t)K * ZWZ_CHUNK_SIZE), p_wave((size_t)K * ZWZ_CHUNK_SIZE), back((size_t)K * ZWZ_CHUNK_SIZE);
+    uint32_t l_serial[K], l_wave[K], l_back[K], st[K];
+    uint64_t poffs[K];
+    for (uint32_t k = 0; k < K; k++) poffs[k] = (uint64_t)k * ZWZ_CHUNK_SIZE;
+    auto same_as_input = [&] {
+        for (uint32_t k = 0; k < K; k++) if (st[k] != ZWZ_INF_END || l_back[k] != lens[k] || memcmp(back.data() + (size_t)k * ZWZ_CHUNK_SIZE, in.data() + offs[k], lens[k])) return false;
+        return true;
+    };
+    c->plan_serial = 1;
+    int rc = zwz_deflate_batch(c, in.data(), offs, lens, K, p_serial.data(), l_serial);
+    c->inflate_serial_header = 1;
+    if (rc == ZWZ_OK) rc = zwz_inflate_batch(c, p_serial.data(), poffs, l_serial, K, back.data(), l_back, st);
+    if (rc != ZWZ_OK) return rc;
+    if (!same_as_input()) { set_error("zwz_ctx_create: codec self-test failed -- three chunks do not survive deflate + inflate on this device even in the kernels' order-free forms"); return ZWZ_E_NO_DEVICE; }
+    if (!keep_plan) {
+        c->plan_serial = 0;
+        rc = zwz_deflate_batch(c, in.data(), offs, lens, K, p_wave.data(), l_wave);
+        if (rc != ZWZ_OK) return rc;
+        bool same = true;
+        for (uint32_t k = 0; k < K; k++) same = same && l_wave[k] == l_serial[k] && !memcmp(p_wave.data() + (size_t)k * ZWZ_CHUNK_SIZE, p_serial.data() + (size_t)k * ZWZ_CHUNK_SIZE, l_serial[k]);
+        if (!same) { c->plan_serial = 1; fprintf(stderr, "zwz: the wave form of the block flush disagrees with the lane-serial one on this device: using the lane-serial kernel\n"); }
+    }
+    if (!keep_hdr) {
+        c->inflate_serial_header = 0;
+        rc = zwz_inflate_batch(c, p_serial.data(), poffs, l_serial, K, back.data(), l_back, st);
+        if (rc != ZWZ_OK) return rc;
+        if (!same_as_input()) { c->inflate_serial_header = 1; fprintf(stderr, "zwz: inflate's wave-built tables decode wrongly on this device: block headers go to lane 0\n"); }
     }
     return ZWZ_OK;
 }
@@ -169,21 +231,54 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cu_count = (uint32_t)cus; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = configure_kernels();
-    if (e == hipSuccess) {
-        // lz_links stands on the lane order of the LDS exchange (see exchange_order_probe_kernel): checked once per context
-        bool holds = false;
-        e = probe_exchange_order(c->stream, &holds);
-        if (e == hipSuccess && !holds) {
-            set_error("zwz_ctx_create: this device's ds_wrxchg_rtn_b32 does not serve same-address lanes in lane order; lz_links cannot run on it");
-            zwz_ctx_destroy(c);
-            return ZWZ_E_NO_DEVICE;
-        }
-    }
-    if (e == hipSuccess) { const int rc = links_self_test(c); if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; } }
     for (int i = 0; i < kNumDeflateStages + 1 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&c->ev_inf[i]);
     if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create"); zwz_ctx_destroy(c); return rc; }
+    if (const uint32_t xk = exp_flags_kernels(), xb = exp_flags_band(); xk | xb)     // never silent: an instrumented build must not pass for the product
+        fprintf(stderr, "zwz: EXPERIMENT BUILD (ZWZ_MATCH_EXP=%u ZWZ_PARSE_EXP=%u ZWZ_ENC_EXP=%u ZWZ_INF_EXP=%u ZWZ_BAND_EXP=%u): timings only, not the product library\n",
+                xk & 255u, (xk >> 8) & 255u, (xk >> 16) & 255u, xk >> 24, xb);
+    // Test switches, read ONCE per context (a stray variable is still honoured, but no launch re-reads the environment: ADVICE r3)
+    if (const char* v = getenv("ZWZ_MATCH")) (void)zwz_ctx_set_option(c, "match", v);
+    if (const char* v = getenv("ZWZ_PLAN")) (void)zwz_ctx_set_option(c, "plan", v);
+    if (const char* v = getenv("ZWZ_INFLATE_HEADER")) (void)zwz_ctx_set_option(c, "inflate_header", v);
+    // Three kernels stand on LDS behaviour the ISA manual does not promise: lz_links on the lane order of
+    // ds_wrxchg_rtn, lz_sort / the wave plan / inflate's wave-built tables on that of ds_add_rtn.  Each is checked here against a
+    // host restatement or its own order-free form; a failed check selects the form that does not need the property, and only a
+    // device on which no search kernel is left gets no context.
+    {
+        bool xchg_ok = false;
+        e = probe_exchange_order(c->stream, &xchg_ok);
+        if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create: exchange-order probe"); zwz_ctx_destroy(c); return rc; }
+        uint32_t bad = 0;
+        const int rc = links_self_test(c, &bad);
+        if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; }
+        const bool links_ok = xchg_ok && !(bad & 1u), sort_ok = !(bad & 2u);
+        if (!links_ok && !sort_ok) {
+            if (bad == 2u || !bad) set_error("zwz_ctx_create: neither ds_wrxchg_rtn_b32 nor ds_add_rtn_u32 serves same-address lanes in lane order on this device: no match search can run on it");
+            zwz_ctx_destroy(c);
+            return ZWZ_E_NO_DEVICE;
+        }
+        if (!links_ok) { c->match_mode = kMatchBand; fprintf(stderr, "zwz: lz_links' exchange order does not hold on this device: every chunk takes the sort + band search (%s)\n", zwz_last_error()); }
+        if (!sort_ok) {
+            c->match_mode = kMatchWalk; c->plan_serial = 1; c->inflate_serial_header = 1;
+            fprintf(stderr, "zwz: the returning LDS add is not served in lane order on this device: chain walk, lane-serial block flush and lane-serial inflate headers (%s)\n", zwz_last_error());
+        }
+    }
+    { const int rc = codec_self_test(c); if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; } }
     *out = c;
+    return ZWZ_OK;
+}
+
+int zwz_ctx_set_option(zwz_ctx* c, const char* name, const char* value) {
+    if (!c || !name || !value) return ZWZ_E_INVALID;
+    const std::string n = name, v = value;
+    if (n == "match") {
+        if (v == "auto" || v.empty()) c->match_mode = kMatchAuto; else if (v == "walk") c->match_mode = kMatchWalk; else if (v == "band") c->match_mode = kMatchBand; else return ZWZ_E_INVALID;
+    } else if (n == "plan") {
+        if (v == "wave" || v.empty()) c->plan_serial = 0; else if (v == "serial") c->plan_serial = 1; else return ZWZ_E_INVALID;
+    } else if (n == "inflate_header") {
+        if (v == "wave" || v.empty()) c->inflate_serial_header = 0; else if (v == "serial") c->inflate_serial_header = 1; else return ZWZ_E_INVALID;
+    } else return ZWZ_E_INVALID;
     return ZWZ_OK;
 }
 
@@ -243,6 +338,7 @@ int zwz_deflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
         a.in = d_in; a.in_off = d_in_off + done; a.in_len = d_in_len + done; a.n = m;
         a.out = d_out + (size_t)done * out_stride; a.out_stride = out_stride; a.out_len = d_out_len + done;
         carve_workspace(c, a);
+        a.match_mode = c->match_mode; a.plan_serial = c->plan_serial;
         HIPCHK(launch_deflate(a, c->stream, c->profiling ? c->ev : nullptr));
         if (c->profiling) {   // profiling serialises slices: stage times are read back per slice
             HIPCHK(hipEventSynchronize(c->ev[kNumDeflateStages]));
@@ -276,7 +372,7 @@ int zwz_inflate_batch_dev(zwz_ctx* c, const uint8_t* d_in, const uint64_t* d_in_
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->inf_order), (size_t)n * sizeof(uint4)));
         c->inf_order_cap = n;
     }
-    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status, c->inf_order};
+    InflateArgs a{d_in, d_in_off, d_in_len, n, d_out, out_stride, d_out_len, d_status, c->inf_order, c->inflate_serial_header};
     if (c->profiling) HIPCHK(hipEventRecord(c->ev_inf[0], c->stream));
     HIPCHK(launch_inflate(a, c->stream));
     if (c->profiling) {

@@ -19,6 +19,11 @@ struct zwz_ctx {
     uint32_t stage_chunks = 0;
     uint32_t cu_count = 0;
     uint32_t chunk_bytes = 0;        // raw bytes per Chunk for zwz_compress_dir; 0 = default (see chunk_bytes_for)
+    // Switches (zwz_ctx_set_option; defaults from ZWZ_MATCH / ZWZ_PLAN / ZWZ_INFLATE_HEADER read ONCE at zwz_ctx_create, or forced by a
+    // failed self-test there).  Every setting produces the same bytes; they differ in which kernels run.
+    uint32_t match_mode = 0;             // zwz::kMatchAuto | kMatchWalk | kMatchBand
+    uint32_t plan_serial = 0;            // 1: lane-serial block flush
+    uint32_t inflate_serial_header = 0;  // 1: block headers and tables on lane 0
     bool profiling = false;
     hipEvent_t ev[zwz::kNumDeflateStages + 1] = {};
     hipEvent_t ev_inf[2] = {};

@@ -603,6 +603,8 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
+uint32_t exp_flags_band() { return (uint32_t)(ZWZ_BAND_EXP); }
+
 hipError_t configure_band_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlaceLdsBytes);
     if (e != hipSuccess) return e;

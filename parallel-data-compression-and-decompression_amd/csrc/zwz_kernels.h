@@ -85,6 +85,8 @@ struct DeflateArgs {
     uint32_t* dense_list;      // chunks that take the sort + band path (lz_dense_list), tickets[kTicketDenseCount] of them
     uint32_t* sparse_list;     // the others that have any bytes: lz_links' work, tickets[kTicketSparseCount] of them
     uint32_t cu_count;         // sizes the persistent grids (0: 256)
+    uint32_t match_mode;       // kMatchAuto (production: lz_dense_list decides per chunk) | kMatchWalk | kMatchBand -- the context's option, same records either way
+    uint32_t plan_serial;      // 1: the lane-serial block flush (plan_serial_kernel) instead of heap + wave
     ChunkInfo* info; BlockInfo* blocks; BlockOut* plans;
     BlockProbe* probes;        // = links (dead once lz_match has run): chunk c's kMaxBlocks probes open ITS link space
     // The chosen record of every match symbol, compact and in stream order (lz_parse -> blockify, encode): a chunk's
@@ -95,7 +97,12 @@ struct InflateArgs {
     const uint8_t* in; const uint64_t* in_off; const uint32_t* in_len; uint32_t n;
     uint8_t* out; uint64_t out_stride; uint32_t* out_len; uint32_t* status;
     uint4* order;              // n entries of scratch (the launch fills it: (offset, length, chunk) by payload length, longest first), or null: as they come
+    uint32_t serial_header;    // 1: block headers and tables by lane 0 alone (inflate_block_rest) -- no ordered LDS adds
 };
+enum : uint32_t { kMatchAuto = 0, kMatchWalk = 1, kMatchBand = 2 };
+// Experiment defines this library was built with (all zero in the product; tools/gpu.sh times builds libzwz_hip_exp.so with one set)
+uint32_t exp_flags_kernels();   // ZWZ_MATCH_EXP | ZWZ_PARSE_EXP << 8 | ZWZ_ENC_EXP << 16 | ZWZ_INF_EXP << 24
+uint32_t exp_flags_band();      // ZWZ_BAND_EXP
 
 constexpr size_t kTicketBytes = 256;
 enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7 };   // indices into DeflateArgs::tickets

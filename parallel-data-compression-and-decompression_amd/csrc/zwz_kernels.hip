@@ -1843,6 +1843,10 @@ struct InflateWaveMem {
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
 
+// kSerialHeader: block headers and tables by lane 0 alone (inflate_block_rest) -- the form that does not depend on the lane order of the
+// returning LDS add; chosen per context when its known-answer test of the wave-built tables fails (zwz_api.cpp), never otherwise.  A
+// template parameter, not a kernel argument: the production kernel's code is untouched by the other form's.
+template <bool kSerialHeader>
 __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                   const uint32_t* __restrict__ in_len, uint32_t n,
                                                                   uint8_t* __restrict__ out, uint64_t out_stride,
@@ -1894,8 +1898,9 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             uint32_t v = 0, ok = 0;
             if (lane == 0) { opos = st.out_pos; ok = inflate_block_type(st, v) ? 1u : 0u; }
             v = __builtin_amdgcn_readfirstlane(v); ok = __builtin_amdgcn_readfirstlane(ok);
-            if (ok && (v == 0u || v == 3u)) {
-                if (lane == 0) kind = inflate_block_rest(st, nullptr, m.lens, v, soff, slen);
+            if (ok && (kSerialHeader || v == 0u || v == 3u)) {
+                if (lane == 0) kind = inflate_block_rest(st, kSerialHeader ? &m.t : nullptr, m.lens, v, soff, slen);
+                if (kSerialHeader) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             } else if (ok) {
                 uint32_t nlen = 288, ndist = 30, good = 1, max_len = 0;
                 if (v == 1u) {
@@ -2356,6 +2361,8 @@ hipError_t launch_links_only(const DeflateArgs& a, hipStream_t s) {
     return launch_links(a, s, false);
 }
 
+uint32_t exp_flags_kernels() { return (uint32_t)(ZWZ_MATCH_EXP) | (uint32_t)(ZWZ_PARSE_EXP) << 8 | (uint32_t)(ZWZ_ENC_EXP) << 16 | (uint32_t)(ZWZ_INF_EXP) << 24; }
+
 hipError_t configure_kernels() {
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(exchange_order_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
@@ -2371,7 +2378,7 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     // Chain-heavy chunks (lz_dense_list: a sample of each chunk's trigrams): positions sorted by (bucket, position), then the banded
     // search (zwz_band.hip).  The rest: chain links, then lz_match's screening pass over them.  ZWZ_MATCH=walk sends every chunk
     // through links + lz_match (its sorted walk included), =band every chunk through the band.
-    const uint32_t which = [] { const char* e = getenv("ZWZ_MATCH"); return e && !strcmp(e, "walk") ? 1u : e && !strcmp(e, "band") ? 2u : 0u; }();   // (read per launch: tests flip it)
+    const uint32_t which = a.match_mode;         // the context's option (zwz_ctx_set_option; ZWZ_MATCH is read once, at zwz_ctx_create)
     // (stage 0 of the profile = everything that prepares the search: marks and lists, chain links of the sparse chunks, the sorted
     // arrays of the chain-heavy ones; stage 1 = the searches themselves: lz_match, lz_match_band)
     if (which == 1u) ZWZ_TRY(launch_links(a, s, false));
@@ -2384,15 +2391,17 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
                        a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u, a.tickets + 40);
-    if ((ZWZ_MATCH_EXP & 16) && getenv("ZWZ_MATCH_TIMES")) {
+#if ZWZ_MATCH_EXP & 16
+    if (getenv("ZWZ_MATCH_TIMES")) {
         uint32_t h[64];
         ZWZ_TRY(hipStreamSynchronize(s));
         ZWZ_TRY(hipMemcpy(h, a.tickets, sizeof h, hipMemcpyDeviceToHost));
         fprintf(stderr, "ZWZ_MATCH_TIMES n=%u stage0=%u stage=%u screen=%u refine=%u search=%u wait=%u flush_slide=%u\n", a.n, h[40], h[46], h[41], h[42], h[43], h[44], h[45]);
     }
+#endif
     if (which != 1u) {
         ZWZ_TRY(launch_match_band(a, s));
-        if (getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads
+        if ((exp_flags_band() & 16u) && getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads
             uint32_t h[64];
             ZWZ_TRY(hipStreamSynchronize(s));
             ZWZ_TRY(hipMemcpy(h, a.tickets, sizeof h, hipMemcpyDeviceToHost));
@@ -2564,8 +2573,10 @@ hipError_t launch_inflate(const InflateArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const uint32_t per = kInflateThreads / 64;
     if (a.order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(1024), 0, s, a.in_off, a.in_len, a.n, a.order);
-    hipLaunchKernelGGL(inflate_kernel, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
-                       a.out_stride, a.out_len, a.status, (const uint4*)a.order);
+    if (a.serial_header) hipLaunchKernelGGL(inflate_kernel<true>, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
+                                            a.out_stride, a.out_len, a.status, (const uint4*)a.order);
+    else hipLaunchKernelGGL(inflate_kernel<false>, dim3((a.n + per - 1) / per), dim3(kInflateThreads), 0, s, a.in, a.in_off, a.in_len, a.n, a.out,
+                            a.out_stride, a.out_len, a.status, (const uint4*)a.order);
 #if ZWZ_INF_EXP & 16
     if (getenv("ZWZ_INF_TIMES")) {
         unsigned long long h[8], z[8] = {0};

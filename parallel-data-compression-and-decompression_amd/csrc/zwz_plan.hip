@@ -586,7 +586,7 @@ __global__ __launch_bounds__(64) void plan_kernel(const ChunkInfo* __restrict__ 
 }
 
 hipError_t launch_plan(const DeflateArgs& a, hipStream_t s) {
-    const bool serial = [] { const char* e = getenv("ZWZ_PLAN"); return e && !strcmp(e, "serial"); }();      // (read per launch: tests flip it)
+    const bool serial = a.plan_serial != 0u;          // the context's option (zwz_ctx_set_option; ZWZ_PLAN is read once, at zwz_ctx_create)
     uint32_t* open_list = reinterpret_cast<uint32_t*>(a.perm) + a.n;          // lz_match's work-order array is dead by now; its first n words are encode's list
     const uint32_t n_blocks = a.n * kMaxBlocks;
     hipLaunchKernelGGL(plan_probe_kernel, dim3(n_blocks), dim3(64), 0, s, a.info, a.blocks, a.probes);

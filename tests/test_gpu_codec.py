@@ -43,32 +43,32 @@ def test_deflate_matches_oracle(codec, oracle, kind):
 
 
 @pytest.mark.parametrize("flavour", ["band", "walk"])
-def test_deflate_match_flavours_agree_with_oracle(codec, oracle, flavour, monkeypatch):
+def test_deflate_match_flavours_agree_with_oracle(zwz, oracle, flavour):
     """Production picks a chunk's match kernel by its chain density (lz_sort + lz_match_band for chain-heavy chunks,
-    lz_match's screening pass for the rest).  ZWZ_MATCH (read per launch) sends EVERY chunk through one of them: each must
+    lz_match's screening pass for the rest).  The context's "match" option sends EVERY chunk through one of them: each must
     give the oracle's payloads on every kind of content -- sparse chunks through the band (mixed-trigram buckets: the
     8-byte words start at the trigram), chain-heavy ones through the walk."""
-    monkeypatch.setenv("ZWZ_MATCH", flavour)
+    codec = zwz.Codec(0, 1024)
+    codec.set_option("match", flavour)
     sizes = [0, 1, 2, 3, 4, 11, 12, 13, 64, 65, 300, 4097, 5632, 5634, 5635, 11266, 20000, 32506, 32507, 40000, 65274, 65284, 65535]
     for kind in corpus.KINDS:
         chunks = [corpus.make(kind, 8100 + i, n) for i, n in enumerate(sizes) if not (kind == "lz" and 20000 < n < 65535)]
         got = codec.deflate_chunks(chunks)
         for c, g in zip(chunks, got):
             assert g == oracle.payload(c), (flavour, kind, len(c))
+    codec.close()
 
 
 @pytest.mark.parametrize("mode", ["wave", "serial"])
-def test_plan_stage_skewed_histograms(codec, oracle, mode, monkeypatch):
-    """The block flush in its two device forms (csrc/zwz_plan.hip: a lane per heap + a wave per block, the default; ZWZ_PLAN=serial:
+def test_plan_stage_skewed_histograms(zwz, oracle, mode):
+    """The block flush in its two device forms (csrc/zwz_plan.hip: a lane per heap + a wave per block, the default; option plan=serial:
     huff_core.h's plan_block on one lane) on symbol statistics the corpora never reach: geometric / Fibonacci-like byte
     frequencies, a distance tree deeper than 15 bits (gen_bitlen's overflow repair), two-symbol and one-symbol chunks (forced
     tree nodes), alphabets that leave long runs of zero and equal code lengths (scan_tree's 16 / 17 / 18 symbols), and
     enough data per chunk for several blocks."""
     import numpy as np
-    if mode == "serial":
-        monkeypatch.setenv("ZWZ_PLAN", "serial")
-    else:
-        monkeypatch.delenv("ZWZ_PLAN", raising=False)
+    codec = zwz.Codec(0, 1024)
+    codec.set_option("plan", mode)
     rs = np.random.RandomState(777)
     chunks = []
     fib = [1, 1]
@@ -93,15 +93,17 @@ def test_plan_stage_skewed_histograms(codec, oracle, mode, monkeypatch):
     got = codec.deflate_chunks(chunks)
     for i, (c, g) in enumerate(zip(chunks, got)):
         assert g == oracle.payload(c), (mode, i, len(c))
+    codec.close()
 
 
-def test_band_path_fuzz_every_kind_and_collision_heavy_data(codec, oracle, monkeypatch):
-    """Every chunk through lz_sort + lz_place + lz_match_band (ZWZ_MATCH=band), on what the production choice would never send there
+def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle):
+    """Every chunk through lz_sort + lz_place + lz_match_band (option match=band), on what the production choice would never send there
     and on what strains its corners: random lengths around the tile size (5 632 sorted entries) and its multiples; alphabets
     whose trigrams collide in zlib's 15-bit hash (mixed buckets: the 8-byte words start at the trigram) with long repeats on top
     (every entry flagged, sharers' chains through every halo); short periods; runs; chunks stitched from different kinds (the
     word format changes from tile to tile)."""
-    monkeypatch.setenv("ZWZ_MATCH", "band")
+    codec = zwz.Codec(0, 1024)
+    codec.set_option("match", "band")
     rs = corpus.splitmix64(90210, 4 * 160)
     kinds = [k for k in corpus.KINDS if k != "lz"]
     chunks = []
@@ -134,6 +136,7 @@ def test_band_path_fuzz_every_kind_and_collision_heavy_data(codec, oracle, monke
             parts.append(corpus.make(kind, 44000 + 4 * i + j, n)); total += n
         chunks.append(b"".join(parts))
     got = codec.deflate_chunks(chunks)
+    codec.close()
     bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
     assert not bad, bad[:10]
 
@@ -224,6 +227,7 @@ def test_deflate_fuzz_large_and_mixed(codec, oracle):
             parts.append(corpus.make(kind, 31000 + 7 * i + j, n)); total += n
         chunks.append(b"".join(parts))
     got = codec.deflate_chunks(chunks)
+    codec.close()
     bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
     assert not bad, bad[:10]
     back, _ = codec.inflate_chunks(got)
@@ -299,6 +303,35 @@ def test_inflate_matches_oracle(codec, oracle):
         w, total, st = oracle.inflate(p)
         assert total <= CHUNK
         assert g == w, (len(p), len(g), len(w), s, st)
+
+
+def test_inflate_serial_header_option_matches_oracle(zwz, oracle):
+    """The order-free form of the block header (option inflate_header=serial: tables by lane 0, inflate_core.h's inflate_block_rest) --
+    what a context falls back to when its known-answer test of the wave-built tables fails -- decodes like the oracle: whole
+    streams of every kind and level, cut streams, and streams with a damaged dynamic header."""
+    import zlib
+    codec = zwz.Codec(0, 1024)
+    codec.set_option("inflate_header", "serial")
+    with pytest.raises(zwz.ZwzError):
+        codec.set_option("inflate_header", "sideways")
+    payloads, seed = [], 6500
+    for kind in corpus.KINDS:
+        for n in [0, 5, 300, 5000, 65535]:
+            seed += 1
+            data = corpus.make(kind, seed, n)
+            for level in (6, 1, 0):
+                z = zlib.compress(data, level)[:CHUNK]
+                payloads += [z, z[:(seed * 7919) % (len(z) + 1)]]
+    z = zlib.compress(corpus.make("text", 9101, 3000), 6)
+    payloads += [z[:k] for k in range(2, 160)]
+    for bit in range(16, 8 * 120, 3):
+        b = bytearray(z); b[bit >> 3] ^= 1 << (bit & 7); payloads.append(bytes(b))
+    got, status = codec.inflate_chunks(payloads)
+    codec.close()
+    for p, g, s in zip(payloads, got, status):
+        w, total, st = oracle.inflate(p, 1 << 20)
+        if total <= CHUNK:
+            assert g == w, (len(p), len(g), len(w), s, st)
 
 
 def test_inflate_truncated_reference_chunk(codec):

@@ -337,7 +337,7 @@ def test_cli_rccl_collectives_single_rank(golden_dir, tmp_path):
     env = dict(os.environ, ZWZ_COMM="rccl", ZWZ_VERBOSE="1", ZWZ_FILE_RECORD=str(rec), ZWZ_GATHER="1")   # (+ the shard gather: sizes all-gathered, nothing to send with one rank)
     r = subprocess.run([_cli(), "compress", str(src), str(dst)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert "over RCCL" in r.stderr and "shards gathered over RCCL" in r.stderr, r.stderr
+    assert "over RCCL" in r.stderr and "shard gather over RCCL done" in r.stderr, r.stderr
     got = {n: open(dst / n, "rb").read() for n in sorted(os.listdir(dst))}
     assert {n: {"size": len(b), "sha256": sha(b)} for n, b in got.items()} == run["shards"]
     r = subprocess.run([_cli(), "decompress", str(dst), str(back)], env=env, capture_output=True, text=True, timeout=300)
@@ -434,3 +434,87 @@ def test_cli_two_ranks_one_shard_with_a_repeated_path(golden_dir, tmp_path):
         b = open(back / rel, "rb").read()
         assert {"size": len(b), "sha256": sha(b)} == want, rel
     assert sum(o[1].count("MD5 mismatch for file:") for o in outs) == run["md5_mismatches"]      # the repeated files verify
+
+
+# ---------------------------------------------------------------------------------------------- idle ranks
+def _two_file_job(tmp_path):
+    """A source tree of two files and its size-descending list: under three ranks the third has nothing to do."""
+    src = tmp_path / "data" / "src"
+    src.mkdir(parents=True)
+    (src / "big.txt").write_bytes(corpus.text_like(71, 150_000))
+    (src / "small.bin").write_bytes(corpus.random_bytes(72, 70_000))
+    rec = tmp_path / "list.txt"
+    rec.write_text("big.txt\nsmall.bin\n")
+    return src, rec
+
+
+def test_compress_dir_idle_rank_writes_nothing(codec, oracle, tmp_path):
+    """main.cpp:44-51: a rank whose index is not below the number of listed files compresses nothing and creates NO shard.
+    Through the HIP library (the CPU tests check the same guard with the oracle as codec)."""
+    src, rec = _two_file_job(tmp_path)
+    dst, want = tmp_path / "dst", tmp_path / "want"
+    dst.mkdir()
+    want.mkdir()
+    for r in range(3):
+        codec.do_compression(str(src), str(dst), str(rec), r, 3)            # rank 2: returns ZWZ_OK (no exception) ...
+        assert oracle.compress_shard(str(src), str(want), str(rec), r, 3) == 0
+    assert sorted(os.listdir(dst)) == ["compressed_0.zwz", "compressed_1.zwz"]      # ... and leaves no compressed_2.zwz
+    for n in os.listdir(dst):
+        assert open(dst / n, "rb").read() == open(want / n, "rb").read(), n
+    codec.do_compression(str(src), str(dst), str(rec), 7, 8)                 # far beyond the list
+    assert sorted(os.listdir(dst)) == ["compressed_0.zwz", "compressed_1.zwz"]
+
+
+def test_cli_three_ranks_two_files_third_rank_is_idle(oracle, tmp_path):
+    """`main compress` as three ranks over a two-file list: two shards, byte-identical with the oracle's three-rank run, the
+    third rank prints the reference's "No file to compress" (main.cpp:50) and the job exits 0."""
+    src, rec = _two_file_job(tmp_path)
+    dst, want = tmp_path / "zwz", tmp_path / "want"
+    want.mkdir()
+    for r in range(3):
+        assert oracle.compress_shard(str(src), str(want), str(rec), r, 3) == 0
+    assert sorted(os.listdir(want)) == ["compressed_0.zwz", "compressed_1.zwz"]
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS="3", ZWZ_DEVICE="0", ZWZ_FILE_RECORD=str(rec), ZWZ_RENDEZVOUS_TIMEOUT="120")
+        procs.append(subprocess.Popen([_cli(), "compress", str(src), str(dst)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "Rank: 2 - No file to compress" in outs[2][0]
+    assert "No file to compress" not in outs[0][0] and "No file to compress" not in outs[1][0]
+    assert sorted(os.listdir(dst)) == ["compressed_0.zwz", "compressed_1.zwz"]      # no third shard, no markers left
+    for n in os.listdir(dst):
+        assert open(dst / n, "rb").read() == open(want / n, "rb").read(), n
+    # and the two shards decode, as three ranks again (fewer shards than ranks: each shard's records are split three ways), to the tree
+    # the oracle decodes
+    back, wback = tmp_path / "back", tmp_path / "wback"
+    wback.mkdir()
+    for n in sorted(os.listdir(want)):
+        oracle.decompress_shard(str(want / n), str(wback))
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS="3", ZWZ_DEVICE="0", ZWZ_RENDEZVOUS_TIMEOUT="120")
+        procs.append(subprocess.Popen([_cli(), "decompress", str(dst), str(back)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert _tree_of(str(back)) == _tree_of(str(wback))
+
+
+# ---------------------------------------------------------------------------------------------- the multi-rank bench path
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (launcher, communicator self-check, per-rank times, job-wide verification) as two ranks on this
+    box's one GPU over gloo -- the same code the driver's --gpus 8 run goes through, minus RCCL (main.cpp:24-41,131,144 are
+    the collectives it stands in for).  Not a measurement."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--files", "200", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--max-batch", "2048", "--oracle-sample", "64"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm"]["ranks_seen"] == 2 and d["comm"]["backend"] == "gloo"
+    assert len(d["ms_per_step_by_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_by_rank"])
+    assert d["verified"]["ok"] and d["verified"]["ranks_failed"] == 0
+    assert d["text"]["verified"]["ok"] and len(d["text"]["ms_per_step_by_rank"]) == 2
+    assert d["value"] > 0 and d["scaling"] == "weak"
