@@ -959,20 +959,39 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
 // reference, whose ranks share everything).
 // rc_in: what went wrong on this rank before it got here (the shard could not be mapped): it then decodes nothing but still
 // takes part in both exchanges with its failure flag -- its peers are waiting there (a collective has no time-out).
+// Device memory: a rank's range need not fit (BASELINE configs[4]: 64 GiB over few ranks).  Phase 1 inflates the range slice by
+// slice and keeps what comes back whole only for the first `res` chunks -- as many slices as the budget allows (free device
+// memory less a margin, or ZWZ_MAX_RANGE_CHUNKS) -- and for the rest keeps the decoded LENGTHS alone (4 bytes a chunk), which is
+// all the exchange needs; phase 2 copies the resident slices out and inflates the others a second time into the slice's own
+// output buffer (the reference streams by construction, decompression.cpp:65-154; inflating twice costs less than it reads).
+// No way out of this function skips an exchange: everything between them runs under a catch-all that turns an exception
+// (std::bad_alloc from a vector or a pool task's closure, a std::filesystem error) into this rank's failure flag.
 int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<FileInst>& insts, DecodeSink& sink, int rank, int nranks,
                        zwz_allgather_u64_fn exchange, void* user, int rc_in) {
+    constexpr uint32_t kFields = 5;
+    const uint64_t kNoFile = ~0ull;
+    // (the exchanges' buffers first: once they exist, nothing below can keep this rank from joining its peers)
+    std::vector<uint64_t> all((size_t)nranks * kFields), flags((size_t)nranks);
+    int rc = rc_in;
+    auto shielded = [&](const char* what, auto&& body) {
+        try { body(); }
+        catch (const std::bad_alloc&) { if (rc == ZWZ_OK) { set_error("out of host memory while %s", what); rc = ZWZ_E_NOMEM; } }
+        catch (const std::exception& e) { if (rc == ZWZ_OK) { set_error("%s: %s", what, e.what()); rc = ZWZ_E_IO; } }
+        catch (...) { if (rc == ZWZ_OK) { set_error("unknown exception while %s", what); rc = ZWZ_E_IO; } }
+    };
     std::vector<Job> jobs;
-    if (rc_in == ZWZ_OK) for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r});
+    shielded("listing the shard's records", [&] { if (rc_in == ZWZ_OK) for (uint32_t i = 0; i < insts.size(); i++) for (const Rec& r : insts[i].order) jobs.push_back({i, r}); });
+    if (rc != ZWZ_OK) jobs.clear();
     const uint64_t T = jobs.size();
     const uint32_t j0 = (uint32_t)(T * (uint64_t)rank / (uint64_t)nranks), j1 = (uint32_t)(T * (uint64_t)(rank + 1) / (uint64_t)nranks);
     const uint32_t n = j1 - j0;
-    int rc = rc_in;
     uint8_t* d_big = nullptr; uint32_t* d_lens = nullptr; uint32_t* d_stat = nullptr;
-    std::vector<uint32_t> lens(n);
+    std::vector<uint32_t> lens;
     Slices sl;
     bool have_slices = false;
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, n ? (n + 1) / 2 + 1 : 1u)));
     const uint32_t nslices = (n + cap - 1) / cap;
+    uint32_t res = 0;                            // chunks [0, res) of the range stay in d_big between the phases (whole slices)
     auto cleanup = [&] {                         // (idempotent: also run by the guard below on any way out)
         (void)hipStreamSynchronize(c->stream);
         if (have_slices) free_slices(sl);
@@ -981,21 +1000,12 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         if (d_stat) { (void)hipFree(d_stat); d_stat = nullptr; }
     };
     struct Cleanup { decltype(cleanup)& f; ~Cleanup() { f(); } } cleanup_guard{cleanup};
-    if (n) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)n * ZWZ_DEV_STRIDE);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), (size_t)n * sizeof(uint32_t));
-        // (no early return on any of these: the failure travels through the exchanges below)
-        if (e != hipSuccess) { (void)hipGetLastError(); set_error("record range of %u chunks does not fit device memory: %s", n, hipGetErrorString(e)); rc = ZWZ_E_NOMEM; }
-        else { rc = make_slices(c, cap, sl); have_slices = rc == ZWZ_OK; }
-    }
     // (declared before the Drain -- destroyed after it has waited: the write tasks reach fds and cursor by reference)
-    std::vector<int> fds(insts.size(), -1);
+    std::vector<int> fds;
     struct CloseFds { std::vector<int>& v; ~CloseFds() { for (int& fd : v) if (fd >= 0) { close(fd); fd = -1; } } } close_fds{fds};
-    std::vector<uint64_t> cursor(insts.size(), 0);
+    std::vector<uint64_t> cursor;
     Pool::Group fill_group[2], write_group;
     Drain drain{pool, {&fill_group[0], &fill_group[1], &write_group}};
-    // ---- phase 1: payloads in, range inflated into d_big, only the decoded lengths come back
     auto start_fill = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
@@ -1012,62 +1022,110 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
             });
         }
     };
-    if (nslices && rc == ZWZ_OK) start_fill(0);
-    for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+    // slice s: payloads to the device, inflated into `target` (cap slots), decoded lengths to d_len_out
+    auto inflate_slice = [&](uint32_t s, uint8_t* target, uint32_t* d_len_out, uint32_t* d_stat_out) -> int {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, m = std::min(n, g0 + cap) - g0;
-        pool.wait(fill_group[b]);
         hipError_t e = hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync"); break; }
-        rc = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, d_big + (size_t)g0 * ZWZ_DEV_STRIDE, ZWZ_DEV_STRIDE, d_lens + g0, d_stat + g0);
-        if (rc) break;
-        e = hipEventRecord(sl.done[b], c->stream);
-        if (e == hipSuccess && s >= 1) e = hipEventSynchronize(sl.done[(s - 1) & 1]);      // the other buffer pair is free again
-        if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
-        if (s + 1 < nslices) start_fill(s + 1);
-    }
-    pool.wait(fill_group[0]); pool.wait(fill_group[1]);
-    if (rc == ZWZ_OK && n) {
-        hipError_t e = hipMemcpyAsync(lens.data(), d_lens, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = hip_fail(e, "decoded lengths");
-    }
-    // Files are created (and truncated) by the rank that holds their first record, BEFORE the exchange: a rank that joins a
-    // file further in opens it only afterwards, so no write can be lost to a late O_TRUNC.
-    for (uint32_t g = j0; g < j1 && rc == ZWZ_OK; g++) {
-        const uint32_t inst = jobs[g].inst;
-        if (g != 0 && jobs[g - 1].inst == inst) continue;
-        const std::string file_path = sink.path_of(inst);
-        sink.make_parent(file_path);
-        fds[inst] = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        if (fds[inst] < 0) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); }
-    }
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync");
+        return zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, target, ZWZ_DEV_STRIDE, d_len_out, d_stat_out);
+    };
+    uint64_t mine[kFields] = {kNoFile, 0, kNoFile, 0, 0};
+    shielded("inflating a record range", [&] {
+        lens.resize(n); fds.assign(insts.size(), -1); cursor.assign(insts.size(), 0);
+        if (n && rc == ZWZ_OK) {
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), (size_t)n * sizeof(uint32_t));
+            // (no early return on any of these: the failure travels through the exchanges below)
+            if (e != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for the lengths of %u chunks: %s", n, hipGetErrorString(e)); rc = ZWZ_E_NOMEM; }
+            else { rc = make_slices(c, cap, sl); have_slices = rc == ZWZ_OK; }
+            if (rc == ZWZ_OK) {
+                // what stays resident between the phases: whole slices, within the budget; a failed allocation halves it, down to nothing
+                uint64_t budget = n;
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b > ((size_t)1 << 30) ? (free_b - ((size_t)1 << 30)) / ZWZ_DEV_STRIDE : 0;
+                if (const char* v = getenv("ZWZ_MAX_RANGE_CHUNKS")) budget = (uint64_t)std::max(0L, atol(v));
+                uint32_t want = (uint32_t)std::min<uint64_t>(nslices, budget / cap);               // slices
+                while (want) {
+                    const uint32_t chunks = std::min(n, want * cap);
+                    if (hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)chunks * ZWZ_DEV_STRIDE) == hipSuccess) { res = chunks; break; }
+                    (void)hipGetLastError(); d_big = nullptr; want /= 2;
+                }
+                if (verbose()) fprintf(stderr, "zwz: split decode: rank %d holds %u of its %u chunks on the device between the phases (%u slices of %u)\n", rank, res, n, nslices, cap);
+            }
+        }
+        // ---- phase 1: payloads in, range inflated; the first `res` chunks stay, of the others only the decoded lengths come back
+        if (nslices && rc == ZWZ_OK) start_fill(0);
+        for (uint32_t s = 0; s < nslices && rc == ZWZ_OK; s++) {
+            const int b = (int)(s & 1u);
+            const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
+            pool.wait(fill_group[b]);
+            rc = inflate_slice(s, g1 <= res ? d_big + (size_t)g0 * ZWZ_DEV_STRIDE : sl.d_out[b], d_lens + g0, d_stat + g0);
+            if (rc) break;
+            hipError_t e = hipEventRecord(sl.done[b], c->stream);
+            if (e == hipSuccess && s >= 1) e = hipEventSynchronize(sl.done[(s - 1) & 1]);      // the other buffer pair is free again
+            if (e != hipSuccess) { rc = hip_fail(e, "hipEventSynchronize"); break; }
+            if (s + 1 < nslices) start_fill(s + 1);
+        }
+        pool.wait(fill_group[0]); pool.wait(fill_group[1]);
+        if (rc == ZWZ_OK && n) {
+            hipError_t e = hipMemcpyAsync(lens.data(), d_lens, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "decoded lengths");
+        }
+        // Files are created (and truncated) by the rank that holds their first record, BEFORE the exchange: a rank that joins a
+        // file further in opens it only afterwards, so no write can be lost to a late O_TRUNC.
+        for (uint32_t g = j0; g < j1 && rc == ZWZ_OK; g++) {
+            const uint32_t inst = jobs[g].inst;
+            if (g != 0 && jobs[g - 1].inst == inst) continue;
+            const std::string file_path = sink.path_of(inst);
+            sink.make_parent(file_path);
+            fds[inst] = open(file_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            if (fds[inst] < 0) { std::lock_guard<std::mutex> l(sink.log_mutex); fprintf(stderr, "Error creating output file: %s\n", file_path.c_str()); }
+        }
+        if (n && rc == ZWZ_OK) {
+            mine[0] = jobs[j0].inst; mine[2] = jobs[j1 - 1].inst;
+            for (uint32_t g = 0; g < n && jobs[j0 + g].inst == mine[0]; g++) mine[1] += lens[g];
+            for (uint32_t g = n; g-- > 0 && jobs[j0 + g].inst == mine[2];) mine[3] += lens[g];
+        }
+    });
+    pool.wait(fill_group[0]); pool.wait(fill_group[1]);      // (an exception may have left fills in flight)
     // ---- exchange: (first file, bytes decoded into it, last file, bytes decoded into it, status) per rank.  Every rank
     // takes part even after a local failure, so that nobody waits for a rank that has given up.
-    constexpr uint32_t kFields = 5;
-    const uint64_t kNoFile = ~0ull;
-    uint64_t mine[kFields] = {kNoFile, 0, kNoFile, 0, (uint64_t)(rc != ZWZ_OK)};
-    if (n && rc == ZWZ_OK) {
-        mine[0] = jobs[j0].inst; mine[2] = jobs[j1 - 1].inst;
-        for (uint32_t g = 0; g < n && jobs[j0 + g].inst == mine[0]; g++) mine[1] += lens[g];
-        for (uint32_t g = n; g-- > 0 && jobs[j0 + g].inst == mine[2];) mine[3] += lens[g];
-    }
-    std::vector<uint64_t> all((size_t)nranks * kFields);
+    if (rc != ZWZ_OK) { mine[0] = kNoFile; mine[1] = 0; mine[2] = kNoFile; mine[3] = 0; }
+    mine[4] = (uint64_t)(rc != ZWZ_OK);
     if (exchange(user, mine, all.data(), kFields) != 0) { cleanup(); set_error("rank exchange failed"); return ZWZ_E_IO; }
     for (int r = 0; r < nranks; r++) if (all[(size_t)r * kFields + 4]) { if (rc == ZWZ_OK) { set_error("rank %d failed while decoding its record range", r); rc = ZWZ_E_IO; } }
     // ---- phase 2: this rank's bytes to their places
-    if (rc == ZWZ_OK && n) {
+    shielded("writing a record range", [&] {
+        if (!(rc == ZWZ_OK && n)) return;
         for (int r = 0; r < rank; r++)                      // what earlier ranks decoded into the file my range starts in
             if (all[(size_t)r * kFields + 2] == mine[0]) cursor[mine[0]] += all[(size_t)r * kFields + 3];
+        const uint32_t first_again = (res + cap - 1) / cap;            // slices from here on are inflated a second time
+        if (first_again < nslices) start_fill(first_again);
         for (uint32_t s = 0; s < nslices; s++) {
             const int b = (int)(s & 1u);
             const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
-            hipError_t e = hipMemcpyAsync(sl.h_out[b], d_big + (size_t)g0 * ZWZ_DEV_STRIDE, (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
+            if (s >= 2) pool.wait(write_group);             // h_out[b] was the slice before last's: its writes must be through (waits for the last slice's too)
+            hipError_t e = hipSuccess;
+            if (g1 <= res) e = hipMemcpyAsync(sl.h_out[b], d_big + (size_t)g0 * ZWZ_DEV_STRIDE, (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
+            else {
+                pool.wait(fill_group[b]);
+                rc = inflate_slice(s, sl.d_out[b], sl.d_olen[b], sl.d_st[b]);
+                if (rc) break;
+                e = hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], (size_t)(g1 - g0) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc = hip_fail(e, "decoded range to host"); break; }
-            if (s >= 1) pool.wait(write_group);             // (two buffer pairs: the copy above overlapped the previous slice's writes)
+            if (g1 > res) {
+                for (uint32_t g = g0; g < g1; g++) if (sl.h_olen[b][g - g0] != lens[g]) { set_error("a chunk decoded to %u bytes the second time, %u the first", sl.h_olen[b][g - g0], lens[g]); rc = ZWZ_E_IO; }
+                if (rc) break;
+                if (s + 1 < nslices) { pool.wait(fill_group[(s + 1) & 1u]); start_fill(s + 1); }     // (h_in of the other pair is free: its slice is on the device or done)
+            }
+            if (s >= 1) pool.wait(write_group);             // (two buffer pairs: the work above overlapped the previous slice's writes)
             for (uint32_t r0 = g0; r0 < g1;) {
                 const uint32_t inst = jobs[j0 + r0].inst;
                 uint32_t r1 = r0;
@@ -1088,12 +1146,12 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
             }
         }
         pool.wait(write_group);
-    }
+    });
+    pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(write_group);
     for (int& fd : fds) if (fd >= 0) { close(fd); fd = -1; }
     cleanup();
     // ---- barrier, then verification by whoever holds a file's last record
     uint64_t flag[1] = {(uint64_t)(rc != ZWZ_OK)};
-    std::vector<uint64_t> flags((size_t)nranks);
     if (exchange(user, flag, flags.data(), 1) != 0) { set_error("rank exchange failed"); return ZWZ_E_IO; }
     for (int r = 0; r < nranks; r++) if (flags[(size_t)r] && rc == ZWZ_OK) { set_error("rank %d failed while writing its record range", r); rc = ZWZ_E_IO; }
     if (rc == ZWZ_OK) {

@@ -219,6 +219,32 @@ def test_cli_multirank_decompress_matches_reference_tree(golden_dir, tmp_path, n
     assert not [n for n in os.listdir(back) if n.startswith(".zwz_")]          # rendezvous markers cleaned up
 
 
+@pytest.mark.parametrize("nranks,budget", [(2, "0"), (2, "4"), (3, "1"), (3, "2")])
+def test_cli_split_decode_streams_a_range_that_does_not_fit(golden_dir, tmp_path, nranks, budget):
+    """One shard split over N ranks whose record ranges do NOT fit the device (BASELINE configs[4]: 64 GiB over few ranks; forced
+    here by ZWZ_MAX_RANGE_CHUNKS, the number of chunks a rank may keep on the device between the two phases): the first slices
+    stay resident, the others keep only their decoded lengths for the exchange and are inflated a second time when their
+    bytes are written (decompression.cpp:65-154 streams by construction).  Same tree as the reference's, same MD5 verdicts."""
+    run = json.load(open(os.path.join(golden_dir, "tree.json")))["runs"]["1"]
+    zdir = tmp_path / "zwz"
+    zdir.mkdir()
+    shutil.copy(os.path.join(golden_dir, "tree_N1", "compressed_0.zwz"), zdir / "compressed_0.zwz")
+    back = tmp_path / "back"
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, ZWZ_RANK=str(r), ZWZ_NRANKS=str(nranks), ZWZ_DEVICE="0", ZWZ_RENDEZVOUS_TIMEOUT="120", ZWZ_MAX_RANGE_CHUNKS=budget, ZWZ_VERBOSE="1")
+        procs.append(subprocess.Popen([_cli(), "decompress", str(zdir), str(back)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    held = [int(l.split("holds ")[1].split(" of its ")[0]) for o in outs for l in o[1].splitlines() if "split decode: rank" in l]
+    total = [int(l.split(" of its ")[1].split(" chunks")[0]) for o in outs for l in o[1].splitlines() if "split decode: rank" in l]
+    assert len(held) == nranks and all(h <= int(budget) for h in held) and any(h < t for h, t in zip(held, total)), (held, total)
+    assert sum(o[1].count("MD5 mismatch for file:") for o in outs) == run["md5_mismatches"]
+    for rel, want in run["decoded"].items():
+        b = open(back / rel, "rb").read()
+        assert {"size": len(b), "sha256": sha(b)} == want, rel
+
+
 def test_cli_ignores_stale_markers_of_a_crashed_run(golden_dir, tmp_path):
     """A run that died leaves its rendezvous files in <dst>.  The next run -- even under the SAME run id -- must not take
     the dead run's list path, nor its completion markers, for its own (csrc/main.cpp: nonce handshake)."""
