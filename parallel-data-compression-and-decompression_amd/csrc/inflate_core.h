@@ -119,12 +119,45 @@ ZWZ_HD int build_decode_table(const uint8_t* lens, uint32_t n, uint16_t* fast, u
     return left > 0 ? 1 : 0;
 }
 
+// The device's fast tables in the form its window decode reads them (inflate_kernel; packed in place by the wave once a block's
+// tables exist): an entry says at once what KIND of symbol starts at a bit offset and how many bits it SKIPS, so that a slot of the
+// speculative window -- 512 of them a round, 7 % of which are symbols -- costs two lookups and no arithmetic on the symbol's value:
+//   literal/length entry   kind << 13 | symbol << 4 | skip       skip = code length (+ the length code's extra bits), 1..15
+//                          kind: 0 literal, 2 end of block, 5 a symbol that is no length code (286 / 287), 7 length code, 3 no entry
+//   distance entry         kind << 13 | code << 5 | skip         skip = code length + extra bits, 1..21; kind: 1 fine, 5 code 30 / 31, 3 no entry
+// (kinds are the window decode's own: kLit, kMatch, kEob, kSlow, kNeed, kErr.)
+constexpr uint32_t kPkLit = 0, kPkMatch = 1, kPkEob = 2, kPkNone = 3, kPkErr = 5, kPkLen = 7;
+ZWZ_HD uint16_t pack_lit_entry(uint32_t e /* classic: sym << 4 | len, 0 = none */) {
+    if (e == 0) return (uint16_t)(kPkNone << 13);
+    const uint32_t l = e & 15u, s = e >> 4;
+    const uint32_t kind = s < 256u ? kPkLit : s == 256u ? kPkEob : s < 286u ? kPkLen : kPkErr;
+    return (uint16_t)(kind << 13 | s << 4 | (l + (kind == kPkLen ? length_extra_bits(s - 257u) : 0u)));
+}
+ZWZ_HD uint16_t pack_dist_entry(uint32_t e) {
+    if (e == 0) return (uint16_t)(kPkNone << 13);
+    const uint32_t l = e & 15u, d = e >> 4;
+    return (uint16_t)((d < 30u ? kPkMatch : kPkErr) << 13 | d << 5 | (l + (d < 30u ? dist_extra_bits(d) : 0u)));
+}
+// classic view of a packed entry (symbol << 4 | code length; 0 = none): what decode_symbol works on
+ZWZ_HD uint32_t unpack_lit_entry(uint32_t e) {
+    const uint32_t kind = e >> 13, s = (e >> 4) & 511u, skip = e & 15u;
+    if (kind == kPkNone) return 0u;
+    return s << 4 | (skip - (kind == kPkLen ? length_extra_bits(s - 257u) : 0u));
+}
+ZWZ_HD uint32_t unpack_dist_entry(uint32_t e) {
+    const uint32_t kind = e >> 13, d = (e >> 5) & 31u, skip = e & 31u;
+    if (kind == kPkNone) return 0u;
+    return d << 4 | (skip - (kind == kPkMatch ? dist_extra_bits(d) : 0u));
+}
+
 // Decode one symbol.  Returns symbol >= 0, -1 if the payload ends inside the code (nothing
-// consumed), -2 if the bits match no code.
+// consumed), -2 if the bits match no code.  kFmt: 0 = classic fast table, 1 = packed literal/length table, 2 = packed distance table.
+template <uint32_t kFmt = 0>
 ZWZ_HD int decode_symbol(BitReader& br, const uint16_t* fast, uint32_t fast_bits, const uint16_t* count,
                          const uint16_t* sorted) {
     if (br.bits < 15) br.refill();
     uint32_t e = fast[br.peek(fast_bits)];
+    if (kFmt == 1u) e = unpack_lit_entry(e); else if (kFmt == 2u) e = unpack_dist_entry(e);
     uint32_t l = e & 15u;
     if (e != 0 && l <= br.bits) { br.drop(l); return (int)(e >> 4); }
     // slow path: canonical walk bit by bit (long codes, invalid codes, or the stream's last bits)
@@ -275,13 +308,15 @@ ZWZ_HD uint32_t inflate_block_rest(InflateState& st, InflateTables* tp, uint8_t*
 // (len << 16) | dist for a match (dist >= 1).  pos[i] = output offset of symbol i.
 // Returns the symbol count; *block_done is set at end-of-block or when decoding stops.
 // out_cap bounds the output slot (65535): a symbol that would cross it stops with kInfOverflow.
+// kPacked: t's two fast tables are in the device's packed form (see pack_lit_entry).
+template <bool kPacked = false>
 ZWZ_HD uint32_t inflate_decode_batch(InflateState& st, const InflateTables& t, uint32_t out_cap, uint32_t* batch,
                                      uint32_t* pos, bool& block_done, uint32_t max_syms = kBatch) {
     BitReader& br = st.br;
     uint32_t k = 0;
     block_done = false;
     while (k < max_syms) {
-        int sym = decode_symbol(br, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym);
+        int sym = decode_symbol<kPacked ? 1u : 0u>(br, t.lit_fast, kLitFastBits, t.lit_count, t.lit_sym);
         if (sym < 0) { st.status = sym == -1 ? kInfNeedInput : kInfDataError; block_done = true; break; }
         if (sym < 256) {
             if (st.out_pos >= out_cap) { st.status = kInfOverflow; block_done = true; break; }
@@ -294,7 +329,7 @@ ZWZ_HD uint32_t inflate_decode_batch(InflateState& st, const InflateTables& t, u
         uint32_t xv = 0, xb = length_extra_bits(c);
         if (!br.take(xb, xv)) { st.status = kInfNeedInput; block_done = true; break; }
         uint32_t len = (c == 28u ? 258u : length_base(c) + 3u + xv);
-        int ds = decode_symbol(br, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym);
+        int ds = decode_symbol<kPacked ? 2u : 0u>(br, t.dist_fast, kDistFastBits, t.dist_count, t.dist_sym);
         if (ds < 0) { st.status = ds == -1 ? kInfNeedInput : kInfDataError; block_done = true; break; }
         if (ds >= 30) { st.status = kInfDataError; block_done = true; break; }
         xb = dist_extra_bits((uint32_t)ds);

@@ -1731,6 +1731,10 @@ __device__ unsigned long long g_inf_times[8];
 #else
 #define ZWZ_ISTAMP(ph) do { } while (0)
 #endif
+#ifndef ZWZ_INF_WAVES
+#define ZWZ_INF_WAVES 5
+#endif
+constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
 constexpr uint32_t kWinParts = 2;          // windows a round may look at
@@ -1838,7 +1842,7 @@ struct InflateWaveMem {
     InflateTables t;
     uint8_t lens[320];
     uint32_t batch[kBatch], pos[kBatch];
-    uint2 sym[kBatch + 1];                    // a round's symbols in orbit order: (kind << 25 | value, bits << 10 | offset from the round's first bit)
+    uint32_t sym[kBatch + 1];                 // a round's symbols in orbit order: bits << 13 | kind << 10 | offset from the round's first bit
     __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
     __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
 };
@@ -1847,7 +1851,7 @@ struct InflateWaveMem {
 // returning LDS add; chosen per context when its known-answer test of the wave-built tables fails (zwz_api.cpp), never otherwise.  A
 // template parameter, not a kernel argument: the production kernel's code is untouched by the other form's.
 template <bool kSerialHeader>
-__global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+__global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                   const uint32_t* __restrict__ in_len, uint32_t n,
                                                                   uint8_t* __restrict__ out, uint64_t out_stride,
                                                                   uint32_t* __restrict__ out_len, uint32_t* __restrict__ status,
@@ -1945,6 +1949,13 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
         }
         kind = __builtin_amdgcn_readfirstlane(kind);
         if (kind == kBlkStop) break;
+        if (kind == kBlkHuffman) {
+            // the two fast tables into the window decode's form (inflate_core.h: pack_lit_entry): kind and bits to skip per entry
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t x = lane; x < (1u << kLitFastBits); x += 64u) m.t.lit_fast[x] = pack_lit_entry(m.t.lit_fast[x]);
+            for (uint32_t x = lane; x < (1u << kDistFastBits); x += 64u) m.t.dist_fast[x] = pack_dist_entry(m.t.dist_fast[x]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         if (kind == kBlkStored) {
             soff = __builtin_amdgcn_readfirstlane(soff); slen = __builtin_amdgcn_readfirstlane(slen);
             opos = __builtin_amdgcn_readfirstlane(opos);
@@ -1984,6 +1995,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
             // back to the sequential decoder for one symbol, which also keeps zlib's exact error and
             // truncation behaviour.
             enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
+            static_assert(kLit == kPkLit && kMatch == kPkMatch && kEob == kPkEob && kSlow == kPkNone && kErr == kPkErr, "the packed entries carry this enum");
             uint32_t bp = 0, opos_u = 0;
             if (lane == 0) { bp = st.br.bit_pos(); opos_u = st.out_pos; }
             bp = __builtin_amdgcn_readfirstlane(bp); opos_u = __builtin_amdgcn_readfirstlane(opos_u);
@@ -2000,7 +2012,11 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 constexpr uint32_t kOrbitEnd = 0xffffu;
 #pragma unroll 1
               for (uint32_t wb = 0; wb < 256u * kWinParts; wb += 256u) {      // wb: this window's first offset
-                uint32_t inf[kWinSlots], val[kWinSlots];
+                // A slot says only what KIND of symbol would start at its bit and how many bits it would take: two table lookups on
+                // packed entries (inflate_core.h), no arithmetic on lengths or distances -- 93 % of the slots are not symbols.  The
+                // values are decoded once per round, by lane i for symbol i, in the pass behind the orbit.  (Round 3 decoded every
+                // slot in full: ~70 vector instructions a slot, half of the kernel's vector work.)
+                uint32_t inf[kWinSlots];
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
                     const uint32_t a = bp + wb + r * 64u + lane;
@@ -2009,35 +2025,14 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
                     const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
                     const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);      // >= 57 valid bits
-                    uint32_t kind = kSlow, nb = 0, v = 0;
                     const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
-                    const uint32_t l = e & 15u, s = e >> 4;
-                    if (e != 0) {
-                        if (s < 256u) { kind = kLit; nb = l; v = s; }
-                        else if (s == 256u) { kind = kEob; nb = l; }
-                        else {
-                            const uint32_t c = s - 257u;
-                            kind = kErr;
-                            if (c < 29u) {
-                                const uint32_t xb = length_extra_bits(c);
-                                const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> l) & ((1u << xb) - 1u));
-                                const uint64_t rest = bits >> (l + xb);
-                                const uint32_t de = m.t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
-                                const uint32_t dl = de & 15u, d = de >> 4;
-                                kind = kSlow;
-                                if (de != 0) {
-                                    kind = kErr;
-                                    if (d < 30u) {
-                                        const uint32_t dxb = dist_extra_bits(d);
-                                        const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> dl) & ((1u << dxb) - 1u));
-                                        kind = kMatch; nb = l + xb + dl + dxb; v = (len << 16) | dist;
-                                    }
-                                }
-                            }
-                        }
-                    }
+                    const uint32_t skip = e & 15u;
+                    const uint32_t de = m.t.dist_fast[(uint32_t)(bits >> skip) & ((1u << kDistFastBits) - 1u)];
+                    const bool is_len = (e >> 13) == kPkLen;
+                    uint32_t kind = is_len ? de >> 13 : e >> 13;                          // (the packed kinds are this enum's values)
+                    const uint32_t nb = skip + (is_len ? de & 31u : 0u);
                     if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
-                    inf[r] = kind | (nb << 3); val[r] = v;
+                    inf[r] = kind | (nb << 3);
                 }
                 // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
                 // It is followed by a scalar loop that does nothing but mark: one v_readlane (the next offset, out of the
@@ -2081,8 +2076,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
                     const uint32_t rank = nsym + rank_in(M[r]);
-                    if (((M[r] >> lane) & 1ull) && rank <= kBatch)
-                        m.sym[rank] = make_uint2(val[r] | (inf[r] & 7u) << 25, (wb + r * 64u + lane) | (inf[r] >> 3) << 10);   // value < 2^25: length < 512, distance <= 32768
+                    if (((M[r] >> lane) & 1ull) && rank <= kBatch) m.sym[rank] = (wb + r * 64u + lane) | inf[r] << 10;
                     nsym += (uint32_t)__popcll(M[r]);
                 }
                 ZWZ_ISTAMP(2);                                                // the orbit, symbols to the batch
@@ -2093,8 +2087,27 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                 {
                     // (bitwise on purpose: with && and || the structurizer turns each test into exec-mask control flow)
                     const uint32_t have = (uint32_t)(lane < nsym);             // nsym >= 1: offset 0 is always reached
-                    const uint2 sy = m.sym[lane];                              // (stale beyond nsym: masked by `have`)
-                    const uint32_t kd = sy.x >> 25, v = sy.x & 0x1ffffffu;
+                    const uint32_t sy = m.sym[lane];                           // (stale beyond nsym: masked by `have`)
+                    const uint32_t kd = (sy >> 10) & 7u, s_off = sy & 0x3ffu, s_nb = sy >> 13;
+                    // the symbol's value, decoded here and only here: lane i reads symbol i's bits again (same ring, same tables)
+                    uint32_t v;
+                    {
+                        const uint32_t a = bp + s_off;
+                        const uint32_t byte = (a >> 3) & (kInfRing - 1u);
+                        const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
+                        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
+                        const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);
+                        const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
+                        const uint32_t s = (e >> 4) & 511u, skip = e & 15u;
+                        const uint32_t c = (s - 257u) & 31u;                                 // (a length code where kd == kMatch; anything elsewhere)
+                        const uint32_t xb = length_extra_bits(c);
+                        const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> ((skip - xb) & 15u)) & ((1u << xb) - 1u));
+                        const uint64_t rest = bits >> skip;
+                        const uint32_t de = m.t.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+                        const uint32_t d = (de >> 5) & 31u, dxb = dist_extra_bits(d) & 15u;
+                        const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> (((de & 31u) - dxb) & 31u)) & ((1u << dxb) - 1u));
+                        v = kd == kMatch ? (len << 16) | dist : kd == kLit ? s : 0u;
+                    }
                     const uint32_t is_lit = have & (uint32_t)(kd == kLit), is_match = have & (uint32_t)(kd == kMatch), mlen = v >> 16;
                     const uint32_t ol = is_lit + is_match * mlen;
                     const uint32_t sc = wave_scan_incl(ol);
@@ -2105,22 +2118,21 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     if (C) {                                               // wave-uniform: the round ends at this symbol
                         const uint32_t lc = (uint32_t)__builtin_ctzll(C);
                         const uint32_t c_kind = (uint32_t)__builtin_amdgcn_readlane((int)kd, (int)lc), c_val = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lc);
-                        const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)lc);
+                        const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)s_off, (int)lc), c_nb = (uint32_t)__builtin_amdgcn_readlane((int)s_nb, (int)lc);
                         opos_new = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)lc);
-                        cur = c_off & 0x3ffu;
+                        cur = c_off;
                         k = lc;
                         if (c_kind == kLit) { stop = kErr; stop_status = kInfOverflow; }
                         else if (c_kind == kMatch) { stop = kErr; stop_status = (c_val & 0xffffu) > opos_new ? kInfDataError : kInfOverflow; }
-                        else if (c_kind == kEob) { cur += c_off >> 10; stop = kEob; }
+                        else if (c_kind == kEob) { cur += c_nb; stop = kEob; }
                         else { stop = c_kind; if (c_kind == kNeed) stop_status = kInfNeedInput; else if (c_kind == kErr) stop_status = kInfDataError; }
                     } else if (nsym > kBatch) {                            // batch full: the next round starts at symbol kBatch
                         k = kBatch;
-                        cur = m.sym[kBatch].y & 0x3ffu;
+                        cur = m.sym[kBatch] & 0x3ffu;
                         opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
                     } else {                                               // plain symbols all the way: the chain leaves the window behind the last of them
                         k = nsym;
-                        const uint32_t l_off = (uint32_t)__builtin_amdgcn_readlane((int)sy.y, (int)(nsym - 1u));
-                        cur = (l_off & 0x3ffu) + (l_off >> 10);
+                        cur = (uint32_t)__builtin_amdgcn_readlane((int)(s_off + s_nb), (int)(nsym - 1u));
                         opos_new = opos_u + (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
                     }
                     m.batch[lane] = v;
@@ -2209,7 +2221,7 @@ __global__ __launch_bounds__(kInflateThreads, 5) void inflate_kernel(const uint8
                     if (lane == 0) {
                         st.br.seek_bit(bp); st.out_pos = opos_u;
                         bool d;
-                        k1 = inflate_decode_batch(st, m.t, kChunk, m.batch, m.pos, d, 1u);
+                        k1 = inflate_decode_batch<true>(st, m.t, kChunk, m.batch, m.pos, d, 1u);
                         d1 = d; nbp = st.br.bit_pos(); nop = st.out_pos; stt = st.status;
                     }
                     k1 = __builtin_amdgcn_readfirstlane(k1); d1 = __builtin_amdgcn_readfirstlane(d1);

@@ -303,6 +303,83 @@ extern "C" uint32_t emu_inflate(const uint8_t* in, uint32_t n, uint8_t* out, uin
     return st.out_pos;
 }
 
+// The device's window decode on PACKED fast tables (inflate_kernel: a slot says only kind + bits, lane i decodes symbol i's value in one
+// pass per round), restated per bit offset and run beside the classic decoder.  For every Huffman block the tables are packed in place
+// (pack_lit_entry / pack_dist_entry); at every true symbol start the slot's (kind, bits) and the value pass's (literal | length, distance)
+// must be what inflate_decode_batch<false> decodes there -- or the slot must say "slow" / "need" / "error", the cases the kernel hands to
+// the sequential decoder, which is then run in its packed form (inflate_decode_batch<true>) and must agree as well.  Returns the number
+// of disagreements (0 = fine); *n_syms / *n_slow count what was checked.
+namespace {
+struct SlotView { uint32_t kind, nb, value; };
+SlotView packed_slot(const uint8_t* in, uint32_t n, const InflateTables& tp, uint32_t a /* absolute bit */) {
+    enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
+    uint64_t bits = 0;
+    { unsigned __int128 wide = 0; for (uint32_t i = 0; i < 9; i++) { const uint32_t at = (a >> 3) + i; wide |= (unsigned __int128)(at < n ? in[at] : 0) << (8 * i); } bits = (uint64_t)(wide >> (a & 7u)); }
+    const int32_t avail = (int32_t)(n * 8u) - (int32_t)a;
+    const uint32_t e = tp.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)], skip = e & 15u;
+    const uint64_t rest = bits >> skip;
+    const uint32_t de = tp.dist_fast[(uint32_t)rest & ((1u << kDistFastBits) - 1u)];
+    const bool is_len = (e >> 13) == kPkLen;
+    SlotView v;
+    v.kind = is_len ? de >> 13 : e >> 13;
+    v.nb = skip + (is_len ? de & 31u : 0u);
+    if (avail <= 0 || (v.kind <= kEob && (int32_t)v.nb > avail)) v.kind = kNeed;
+    // the value pass (kernel: "the symbol's value, decoded here and only here")
+    const uint32_t s = (e >> 4) & 511u, c = (s - 257u) & 31u, xb = length_extra_bits(c);
+    const uint32_t len = length_base(c) + 3u + ((uint32_t)(bits >> ((skip - xb) & 15u)) & ((1u << xb) - 1u));
+    const uint32_t d = (de >> 5) & 31u, dxb = dist_extra_bits(d) & 15u;
+    const uint32_t dist = dist_base(d) + 1u + ((uint32_t)(rest >> (((de & 31u) - dxb) & 31u)) & ((1u << dxb) - 1u));
+    v.value = v.kind == kMatch ? (len << 16) | dist : v.kind == kLit ? s : 0u;
+    return v;
+}
+}  // namespace
+
+extern "C" uint32_t emu_packed_window_check(const uint8_t* in, uint32_t n, uint64_t* n_syms, uint64_t* n_slow) {
+    enum : uint32_t { kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kNeed = 4, kErr = 5 };
+    InflateState st;
+    static InflateTables t, tp;
+    uint8_t lens[320];
+    uint32_t bad = 0;
+    *n_syms = 0; *n_slow = 0;
+    if (!inflate_begin(st, in, n)) return 0;
+    for (;;) {
+        uint32_t src = 0, len = 0;
+        const uint32_t kind = inflate_block_header(st, t, lens, src, len);
+        if (kind == kBlkStop) break;
+        if (kind == kBlkStored) { st.out_pos += len; if (st.status != kInfRunning) break; }
+        else {
+            tp = t;
+            for (uint32_t x = 0; x < (1u << kLitFastBits); x++) { tp.lit_fast[x] = pack_lit_entry(t.lit_fast[x]); if (unpack_lit_entry(tp.lit_fast[x]) != t.lit_fast[x]) bad++; }
+            for (uint32_t x = 0; x < (1u << kDistFastBits); x++) { tp.dist_fast[x] = pack_dist_entry(t.dist_fast[x]); if (unpack_dist_entry(tp.dist_fast[x]) != t.dist_fast[x]) bad++; }
+            bool done = false;
+            while (!done) {
+                const uint32_t bp = st.br.bit_pos(), op = st.out_pos;
+                InflateState sp = st;                                   // the packed sequential decoder from the same state
+                uint32_t b1[1], p1[1], b2[1], p2[1];
+                bool d2 = false;
+                const uint32_t k = inflate_decode_batch<false>(st, t, 1u << 30, b1, p1, done, 1u);
+                const uint32_t k2 = inflate_decode_batch<true>(sp, tp, 1u << 30, b2, p2, d2, 1u);
+                if (k != k2 || d2 != done || sp.status != st.status || sp.out_pos != st.out_pos || (!done && sp.br.bit_pos() != st.br.bit_pos()) || (k && (b1[0] != b2[0] || p1[0] != p2[0]))) bad++;
+                const SlotView v = packed_slot(in, n, tp, bp);
+                (*n_syms)++;
+                if (v.kind == kSlow || v.kind == kNeed || v.kind == kErr) { (*n_slow)++; continue; }      // the kernel stops the round here and asks the sequential decoder
+                if (k == 1) {                                            // a literal or a match was decoded
+                    const bool want_match = b1[0] >= 256u;
+                    if (v.kind != (want_match ? kMatch : kLit) || v.value != b1[0] || bp + v.nb != st.br.bit_pos()) bad++;
+                } else if (done && st.status == kInfRunning) {           // end of block
+                    if (v.kind != kEob || bp + v.nb != st.br.bit_pos()) bad++;
+                } else if (st.status == kInfDataError && st.out_pos == op) {
+                    // a distance too far back is the batch pass's business (it knows the output position): the slot decodes it as a match
+                    if (v.kind != kMatch) bad++;
+                } else bad++;                                            // the classic decoder stopped for need / error where the slot saw a plain symbol
+            }
+            if (st.status != kInfRunning) break;
+        }
+        if (st.last) break;
+    }
+    return bad;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Lane-emulated block-parallel parse (mirrors the lz_parse kernel step by step: per 64-position
 // block, transitions -> orbit marking by pointer doubling -> bit scatter into 8-word rings ->

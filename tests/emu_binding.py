@@ -26,6 +26,8 @@ def load():
     lib.emu_plan_split_check.restype = ctypes.c_uint32
     lib.emu_plan_split_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
     lib.emu_overflow_hits.restype = ctypes.c_uint64
+    lib.emu_packed_window_check.restype = ctypes.c_uint32
+    lib.emu_packed_window_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.emu_parse_blocks_check.restype = ctypes.c_int
     lib.emu_parse_blocks_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
     return lib

@@ -164,3 +164,25 @@ def test_deep_distance_tree_chunks_reach_the_repair(emu, oracle):
         h0 = emu.emu_overflow_hits()
         assert emu_binding.chunk_stream(emu, data) == oracle.deflate6(data)
         assert emu.emu_overflow_hits() - h0 >= 1, seed
+
+
+def test_packed_window_decode_agrees_with_the_classic_decoder(emu):
+    """inflate's fast tables in their packed form (csrc/inflate_core.h: an entry = kind + bits to skip) and the two things the kernel does
+    with them -- a slot's (kind, bits) and the once-per-round value pass -- against decode_symbol on the classic tables, at every symbol
+    start of streams of every kind and level, whole, cut and damaged (decompress_chunk(), decompression.cpp:11-37, ignores zlib's
+    return codes: whatever precedes the damage must decode the same)."""
+    import ctypes
+    total = slow = 0
+    rs = corpus.splitmix64(4242, 64)
+    for i, kind in enumerate(corpus.KINDS):
+        for j, n in enumerate((300, 5000, 65535)):
+            data = corpus.make(kind, 5100 + 7 * i + j, n)
+            for level in (6, 1, 9):
+                z = zlib.compress(data, level)[:65535]
+                variants = [z, z[:len(z) * 2 // 3]]
+                b = bytearray(z); b[len(b) // 2] ^= 1 << int(rs[(i + j) % 64] % 8); variants.append(bytes(b))
+                for v in variants:
+                    a, c = ctypes.c_uint64(), ctypes.c_uint64()
+                    assert emu.emu_packed_window_check(v, len(v), ctypes.byref(a), ctypes.byref(c)) == 0, (kind, n, level, len(v))
+                    total += a.value; slow += c.value
+    assert total > 200000 and 0 < slow < total // 20

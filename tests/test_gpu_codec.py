@@ -227,7 +227,6 @@ def test_deflate_fuzz_large_and_mixed(codec, oracle):
             parts.append(corpus.make(kind, 31000 + 7 * i + j, n)); total += n
         chunks.append(b"".join(parts))
     got = codec.deflate_chunks(chunks)
-    codec.close()
     bad = [(i, len(c)) for i, (c, g) in enumerate(zip(chunks, got)) if g != oracle.payload(c)]
     assert not bad, bad[:10]
     back, _ = codec.inflate_chunks(got)

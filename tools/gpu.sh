@@ -7,6 +7,7 @@
 #   tools/gpu.sh times  <kernel> <workload> <files> [bits]   per-phase cycle stamps of band|match|parse|enc|inf: an instrumented build
 #                                                      (-DZWZ_<K>_EXP=16|bits) goes to libzwz_hip_exp.so and is loaded through ZWZ_LIB;
 #                                                      the product library libzwz_hip.so is NEVER rebuilt or replaced by this script
+#   tools/gpu.sh variant <tag> "<flags>" [bench args]  a build with other compile-time constants (libzwz_hip_exp.so too) and one bench run on it
 #   tools/gpu.sh soak   <tag> [chunks] [seed]          tools/soak_gpu.py
 #   tools/gpu.sh refresh <tag>                         the evidence behind DESIGN.md's tables: prof of both headline workloads at full
 #                                                      size -> profiles/<tag>_*_rocprofv3_summary.txt + profiles/traffic_*.json, then the default bench line
@@ -77,6 +78,12 @@ times)
              enc) D=ZWZ_ENC_EXP; E=ZWZ_ENC_TIMES;; inf) D=ZWZ_INF_EXP; E=ZWZ_INF_TIMES;; *) echo "times: band|match|parse|enc|inf"; exit 2;; esac
   make -C $PKG EXP_FLAGS="-D$D=$X" libzwz_hip_exp.so > $R/gpurun_out/exp_build.log 2>&1 || { echo "experiment build failed"; tail -30 $R/gpurun_out/exp_build.log; exit 1; }
   cd $R && ZWZ_LIB=$PKG/libzwz_hip_exp.so env $E=1 timeout -k 10 400 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --workload $W --files $F 2>&1 | grep -E "$E|EXPERIMENT|stage_ms" | cut -c1-700 ;;
+variant)   # <tag> "<compiler flags>" [bench.py args ...]: a build with other constants (e.g. -DZWZ_INF_WAVES=4) as libzwz_hip_exp.so, one bench run on it
+  TAG=${1:-v}; FL=$2; shift; shift
+  make -C $PKG EXP_FLAGS="$FL" libzwz_hip_exp.so > $R/gpurun_out/exp_build.log 2>&1 || { echo "variant build failed"; tail -30 $R/gpurun_out/exp_build.log; exit 1; }
+  cd $R && ZWZ_LIB=$PKG/libzwz_hip_exp.so timeout -k 10 600 python3 bench.py "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; rc=$?
+  tail -c 400 gpurun_out/bench_$TAG.err; echo "variant $FL:"; [ $rc -eq 0 ] && bench_table gpurun_out/bench_$TAG.json
+  exit $rc ;;
 soak)
   TAG=${1:-s}; N=${2:-40000}; SEED=${3:-3}
   cd $R && timeout -k 10 900 python tools/soak_gpu.py $N $SEED > gpurun_out/soak_$TAG.log 2>&1 || { echo "soak failed"; tail -20 gpurun_out/soak_$TAG.log; exit 1; }
