@@ -341,39 +341,60 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
             if (tid == 0) { s_grp[0] = 0; s_grp[1] = 0; s_nflag = 0; s_nrun = 0; }
             if (tid < 132u) s_bin[tid] = 0;
             __syncthreads();                                                  // (also: the chunk's bytes are in place)
-            // ---- the tile's entries and the 128 in front of them: positions from lz_place's array, buckets from the bytes
+            // ---- the tile's entries and the 128 in front of them: positions from lz_place's array; bucket AND the eight comparison bytes
+            // out of ONE read of the four dwords that hold bytes p .. p + 10 (round 3 read the trigram here and then, in a second phase,
+            // the trigram again, the previous entry's, and two unaligned words behind it: ten dword gathers an entry where four do, and
+            // both phases were the LDS pipe's -- 12 % of the kernel)
+            bool mixed = false;
             {
                 const uint32_t pw[4] = {v_next.x, v_next.y, v_next.z, v_next.w};
                 if (8u * tid + a >= kBand) {                                    // (before the array's start: halo words, set above)
+                    uint32_t prev_w = 0, prev_t = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 8; j++) {
-                        const uint32_t p = (pw[j >> 1] >> (16u * (j & 1u))) & 0xffffu, x = load_u32(sdata, p);
-                        if (8u * tid + j < m) S[8u * tid + j] = band_word(hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu), p);
+                        const uint32_t p = (pw[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                        const uint32_t* d = reinterpret_cast<const uint32_t*>(sdata) + (p >> 2);
+                        const uint32_t w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3];           // bytes (p & ~3) .. + 15: p + 10 <= (p & ~3) + 13
+                        const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, p & 3u) & 0xffffffu;
+                        const uint32_t word = band_word(hash3(x & 0xffu, (x >> 8) & 0xffu, x >> 16), p);
+                        const bool up = (p & 3u) != 0u;                                       // bytes p + 3 .. start in w1 (p & 3 >= 1) or in w0
+                        const uint32_t ea = up ? w1 : w0, eb = up ? w2 : w1, ec = up ? w3 : w2, sh = (p + 3u) & 3u;
+                        if (8u * tid + j < m) {
+                            S[8u * tid + j] = word;
+                            E[8u * tid + j] = make_uint2(__builtin_amdgcn_alignbyte(eb, ea, sh), __builtin_amdgcn_alignbyte(ec, eb, sh));
+                            if (j) mixed |= band_hash(word) == band_hash(prev_w) && x != prev_t;      // one bucket, two trigrams (j = 0: below)
+                        }
+                        prev_w = word; prev_t = x;
                     }
                 }
                 v_next = spos_of(a + kBandTile);                                // (a and 128 are multiples of 8)
             }
             __syncthreads();
             ZWZ_STAMP(1);
-            // ---- build
+            // ---- "pure" (every bucket of the tile holds one trigram only: the words start behind the trigram) unless two neighbours of one
+            // bucket differ in their trigrams -- then the words are rebuilt from the trigram on.  Neighbours inside a thread's eight were
+            // compared above; here every thread looks across the seam in front of its first entry.
             bool pure;
             {
-                bool mixed = false;
-#pragma unroll 2
-                for (uint32_t i = tid; i < m; i += kBandThreads) {
-                    const uint32_t w = S[i], wp = i ? S[i - 1u] : kBandHaloWord, q = band_pos(w);
-                    const uint32_t tg = load_u32(sdata, q), tp = load_u32(sdata, band_pos(wp));
-                    E[i] = make_uint2(load_u32(sdata, q + 3u), load_u32(sdata, q + 7u));   // (a halo word reads position 0's bytes: never compared)
+                const uint32_t i = 8u * tid;
+                if (i && i < m) {
+                    const uint32_t w = S[i], wp = S[i - 1u];
+                    const uint32_t tg = load_u32(sdata, band_pos(w)), tp = load_u32(sdata, band_pos(wp));
                     mixed |= w != kBandHaloWord && wp != kBandHaloWord && band_hash(w) == band_hash(wp) && ((tg ^ tp) & 0xffffffu) != 0u;
                 }
                 pure = !__syncthreads_or((int)mixed);
                 if (!pure) {
-                    for (uint32_t i = tid; i < m; i += kBandThreads) { const uint32_t q = band_pos(S[i]); E[i] = make_uint2(load_u32(sdata, q), load_u32(sdata, q + 4u)); }
+                    for (uint32_t i2 = tid; i2 < m; i2 += kBandThreads) { const uint32_t q = band_pos(S[i2]); E[i2] = make_uint2(load_u32(sdata, q), load_u32(sdata, q + 4u)); }
                 }
             }
             const uint32_t off = pure ? 3u : 0u, deep = pure ? 11u : 8u;
             auto Sf = [&](uint32_t i) { return S[i]; };
             ZWZ_STAMP(2);
+            // (Tried in round 4 and dropped: the bucket's start from a scan of head flags -- a max-scan over the wave plus the last head of the
+            // two blocks in front -- and ONE gather to check that the farthest candidate so found is in reach, the binary search only for
+            // the entries that fail the check.  On the text corpus nearly every wave holds such an entry (a rare trigram's candidates lie
+            // further back than MAX_DIST for every position in the chunk's second half), so the search ran anyway, behind the scan and a
+            // barrier: this phase 3.93 M -> 5.45 M cycles >> 8 per 10 000 chunks, 6.56 M with the fallback's searches advancing together.)
             // ---- count (thread <-> entries kBand + tid + 1024 j: the searches of a thread's entries advance together)
             {
                 constexpr uint32_t kOwnPer = (kBandTile + kBandThreads - 1) / kBandThreads;
@@ -553,7 +574,11 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
                 const uint32_t c = ck[i - kBand], cnt = c & 0xffu, k1 = c >> 8;
                 const uint32_t p = band_pos(S[i]), la = L - p;
                 const uint32_t max_len = la < kMaxMatch ? la : kMaxMatch, nice = la < kNiceLen ? la : kNiceLen;
+                // (sixteen bytes behind the compared ones, not eight: with eight, some lane of the wave fell out into match_len_from's serial loop
+                // at nearly every hop -- a third identical word in a row is a 2-3 % event per lane, i.e. an 85 % event per wave --
+                // and a hop cost ~1 500 cycles; sixteen settle all but ~1 in 2 000 visits)
                 const uint32_t own2_lo = load_u32(sdata, p + deep), own2_hi = load_u32(sdata, p + deep + 4u);
+                const uint32_t own3_lo = load_u32(sdata, p + deep + 8u), own3_hi = load_u32(sdata, p + deep + 12u);
                 uint32_t best = 0, best_pos = 0, snap = 0xffffffffu;
                 uint32_t j = on ? i - k1 : kBand;
                 uint32_t w = S[j];
@@ -564,9 +589,10 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
                     const bool more = link != kBandNoLink && i - link <= cnt;
                     const uint32_t wn = S[more ? link : kBand];
                     const uint32_t x0 = load_u32(sdata, q + deep) ^ own2_lo, x1 = load_u32(sdata, q + deep + 4u) ^ own2_hi;
+                    const uint32_t x2 = load_u32(sdata, q + deep + 8u) ^ own3_lo, x3 = load_u32(sdata, q + deep + 12u) ^ own3_hi;
                     if (walking) {
                         if (k > kShortChain && snap == 0xffffffffu) snap = best ? entry_pack(best, p - best_pos) : 0u;
-                        uint32_t len = (x0 | x1) ? deep + (band_ctz64(x0, x1) >> 3) : match_len_from(sdata, q, p, deep + 8u, max_len);
+                        uint32_t len = (x0 | x1) ? deep + (band_ctz64(x0, x1) >> 3) : (x2 | x3) ? deep + 8u + (band_ctz64(x2, x3) >> 3) : match_len_from(sdata, q, p, deep + 16u, max_len);
                         len = len < max_len ? len : max_len;
                         if (len > best) { best = len; best_pos = q; }
                         walking = more && best < nice;

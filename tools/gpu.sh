@@ -45,7 +45,8 @@ PY
 case $cmd in
 tests)
   TAG=${1:-t}; shift
-  cd $R && timeout -k 10 1100 python -m pytest ${@:-tests} -m gpu -x -q > gpurun_out/tests_$TAG.log 2>&1; rc=$?
+  [ $# -eq 0 ] && set -- tests
+  cd $R && timeout -k 10 1100 python -m pytest "$@" -m gpu -x -q > gpurun_out/tests_$TAG.log 2>&1; rc=$?
   tail -4 gpurun_out/tests_$TAG.log
   [ $rc -ne 0 ] && { echo "GPU TESTS FAILED rc=$rc"; tail -60 gpurun_out/tests_$TAG.log; }
   exit $rc ;;
