@@ -1076,6 +1076,9 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
             if ((nonlit >> e0) == 0) {
                 marks = validm & ~((1ull << e0) - 1ull);                 // only literals from the entry on
             } else {
+                // (Round 4, measured and dropped again: the orbit by a scalar hop -- v_readlane + a few scalar instructions a symbol, as in
+                // inflate -- for the chunks lz_dense_list marks chain-heavy: text 15.3 -> 16.9 ms, 7 KB image-like files 6.7 -> 11.4 ms per
+                // 100 000 chunks: a block of mostly literals is sixty hops, and six rounds of doubling cost less than fifteen hops.)
                 for (uint32_t round = 0; round < 6; round++) {
                     if (((marks >> lane) & 1ull) && succ < 64u) m.flag[succ] = 1;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1737,7 +1740,10 @@ __device__ unsigned long long g_inf_times[8];
 constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;
 constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
-constexpr uint32_t kWinParts = 2;          // windows a round may look at
+#ifndef ZWZ_WIN_PARTS
+#define ZWZ_WIN_PARTS 2
+#endif
+constexpr uint32_t kWinParts = ZWZ_WIN_PARTS;   // windows a round may look at (offsets from the round's first bit stay below 1024: <= 4).  Three: text 25.0 -> 24.6 ms, 7 KB image-like files 13.9 -> 15.5 ms
 
 constexpr uint32_t kOwnCap = 1024;         // batch bytes the per-byte owner map covers (a batch is <= 64 symbols: ~300 bytes on text)
 
