@@ -563,6 +563,11 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
             }
             __syncthreads();
             ZWZ_STAMP(9);
+            // (Round 4, measured and dropped: the walks measured first -- the same chase through the links, nothing compared -- and then taken
+            // longest first.  Taken 64 at a time in array order a third of the lanes are busy, sorted by length four fifths
+            // (tools/exp/band_pass2_skew.py), and nothing the first pass leaves behind predicts the length.  The walk itself fell by 18 %
+            // (6.99 M -> 5.75 M cycle units per 10 000 chunks), measuring and sorting cost 2.75 M: a hop's price is its lanes' LDS gathers,
+            // not the trip.  Text match stage 70.4 -> 73.7 ms.)
             const uint32_t n_flag = s_nflag;
             for (;;) {
                 uint32_t g = 0;
