@@ -5,12 +5,18 @@ root = sys.argv[1]
 out = []
 # A context's self-tests launch the product's own kernels on a handful of chunks (lz_links: 3 workgroups): they are left
 # out of every per-launch figure -- only dispatches of the batch's grid size (the largest seen per kernel) count.
+def short(name):
+    """zwz::lz_sort_kernel(...) / void zwz::inflate_kernel<false>(...) -> zwz::lz_sort_kernel / zwz::inflate_kernel (template arguments dropped:
+    the serial-header flavour of inflate only runs in a context's self-test and is filtered out by its grid size)"""
+    name = name.split("(")[0]
+    if name.startswith("void "): name = name[5:]
+    return name.split("<")[0][:40]
 def batch_rows(rows, name_key, grid_key):
     rows = [r for r in rows if "zwz" in r.get(name_key, "")]
     top = collections.defaultdict(int)
     for r in rows:
-        top[r[name_key]] = max(top[r[name_key]], int(r[grid_key]))
-    return [r for r in rows if int(r[grid_key]) * 4 >= top[r[name_key]]]
+        top[short(r[name_key])] = max(top[short(r[name_key])], int(r[grid_key]))
+    return [r for r in rows if int(r[grid_key]) * 4 >= top[short(r[name_key])]]
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     out.append("== kernel stats over the batch launches (%s)" % os.path.relpath(f, root))
     dur = collections.defaultdict(list)
@@ -24,7 +30,7 @@ cnt = collections.defaultdict(int)
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in batch_rows(list(csv.DictReader(open(f))), "Kernel_Name", "Grid_Size"):
         k = row.get("Kernel_Name", "")
-        k = k.split("(")[0][:40]
+        k = short(k)
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] in ("SQ_WAVES", "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE"): cnt[(k, row["Counter_Name"])] += 1
 out.append("== PMC sums over all dispatches (per kernel)")
@@ -40,7 +46,7 @@ for f in glob.glob(os.path.join(root, "pmc3", "**", "*counter_collection.csv"), 
     for row in batch_rows(list(csv.DictReader(open(f))), "Kernel_Name", "Grid_Size"):
         k = row.get("Kernel_Name", "")
         if row["Counter_Name"] == "FETCH_SIZE":
-            calls[k.split("(")[0][:40]] = calls.get(k.split("(")[0][:40], 0) + 1
+            calls[short(k)] = calls.get(short(k), 0) + 1
 traffic = {}
 for k, d in agg.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d and calls.get(k):
