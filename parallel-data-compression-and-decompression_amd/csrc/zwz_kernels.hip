@@ -1738,7 +1738,7 @@ __device__ unsigned long long g_inf_times[8];
 #define ZWZ_INF_WAVES 5
 #endif
 constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;
-constexpr uint32_t kInfRing = 2048, kInfFill = 1024;
+constexpr uint32_t kInfRing = 2048, kInfFill = 1024, kInfMirror = 48;   // ring, refill step, bytes of the ring's start repeated behind its end (a window fetch reads 36 consecutive bytes)
 constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
 #ifndef ZWZ_WIN_PARTS
 #define ZWZ_WIN_PARTS 2
@@ -1850,7 +1850,7 @@ struct InflateWaveMem {
     uint32_t batch[kBatch], pos[kBatch];
     uint32_t sym[kBatch + 1];                 // a round's symbols in orbit order: bits << 13 | kind << 10 | offset from the round's first bit
     __attribute__((aligned(16))) uint8_t ownb[kOwnCap];   // per output byte of a batch: 1 + the batch symbol that writes it (batches of <= kOwnCap bytes)
-    __attribute__((aligned(16))) uint8_t ring[kInfRing + 16];
+    __attribute__((aligned(16))) uint8_t ring[kInfRing + kInfMirror];
 };
 
 // kSerialHeader: block headers and tables by lane 0 alone (inflate_block_rest) -- the form that does not depend on the lane order of the
@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
             uint4 v = make_uint4(0, 0, 0, 0);
             if (o < nin16) v = *reinterpret_cast<const uint4*>(src + o);
             *reinterpret_cast<uint4*>(m.ring + (o & (kInfRing - 1u))) = v;
-            if ((o & (kInfRing - 1u)) == 0) *reinterpret_cast<uint4*>(m.ring + kInfRing) = v;   // wrap-around mirror
+            if ((o & (kInfRing - 1u)) < kInfMirror) *reinterpret_cast<uint4*>(m.ring + kInfRing + (o & (kInfRing - 1u))) = v;   // wrap-around mirror
             fill_end += kInfFill;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2022,22 +2022,32 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
                 // packed entries (inflate_core.h), no arithmetic on lengths or distances -- 93 % of the slots are not symbols.  The
                 // values are decoded once per round, by lane i for symbol i, in the pass behind the orbit.  (Round 3 decoded every
                 // slot in full: ~70 vector instructions a slot, half of the kernel's vector work.)
+                // (a lane's four slots are 64 bits apart: the same byte alignment and bit shift, eight bytes on -- ONE address and nine
+                // consecutive dwords serve all four, where four separate fetches were twelve reads and four address computations)
                 uint32_t inf[kWinSlots];
+                const uint32_t near_end_s = __builtin_amdgcn_readfirstlane((uint32_t)(bp + wb + 64u * kWinSlots + 64u > total_bits));   // can a symbol of this window reach past the payload?  (a symbol is < 64 bits)
+                const uint32_t a0 = bp + wb + lane;
+                const uint32_t byte0 = (a0 >> 3) & (kInfRing - 1u);
+                uint32_t wd[2u * kWinSlots + 1u];
+                {
+                    const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte0 >> 2);   // (reads up to 35 bytes past byte0 & ~3: the ring's mirror)
+#pragma unroll
+                    for (uint32_t i = 0; i < 2u * kWinSlots + 1u; i++) wd[i] = w[i];
+                }
 #pragma unroll
                 for (uint32_t r = 0; r < kWinSlots; r++) {
-                    const uint32_t a = bp + wb + r * 64u + lane;
-                    const int32_t avail = (int32_t)total_bits - (int32_t)a;
-                    const uint32_t byte = (a >> 3) & (kInfRing - 1u);
-                    const uint32_t* w = reinterpret_cast<const uint32_t*>(m.ring) + (byte >> 2);
-                    const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], byte & 3u), hi = __builtin_amdgcn_alignbyte(w[2], w[1], byte & 3u);
-                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a & 7u);      // >= 57 valid bits
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(wd[2u * r + 1u], wd[2u * r], byte0), hi = __builtin_amdgcn_alignbyte(wd[2u * r + 2u], wd[2u * r + 1u], byte0);   // (the shift's low two bits count)
+                    const uint64_t bits = (((uint64_t)hi << 32) | lo) >> (a0 & 7u);     // >= 57 valid bits
                     const uint32_t e = m.t.lit_fast[(uint32_t)bits & ((1u << kLitFastBits) - 1u)];
                     const uint32_t skip = e & 15u;
                     const uint32_t de = m.t.dist_fast[(uint32_t)(bits >> skip) & ((1u << kDistFastBits) - 1u)];
                     const bool is_len = (e >> 13) == kPkLen;
                     uint32_t kind = is_len ? de >> 13 : e >> 13;                          // (the packed kinds are this enum's values)
                     const uint32_t nb = skip + (is_len ? de & 31u : 0u);
-                    if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
+                    if (near_end_s) {                                             // (scalar: the payload's last bits -- a symbol that would reach past them, or starts past them)
+                        const int32_t avail = (int32_t)total_bits - (int32_t)(a0 + r * 64u);
+                        if (avail <= 0 || (kind <= kEob && (int32_t)nb > avail)) kind = kNeed;
+                    }
                     inf[r] = kind | (nb << 3);
                 }
                 // The real symbols are the orbit of offset 0 under "offset -> offset + bits of the symbol decoded there".
