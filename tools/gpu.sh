@@ -64,6 +64,8 @@ trace)
   kernel_table $O/trace; tail -c 300 $O/trace.log ;;
 prof)
   TAG=${1:-p}; W=${2:-text}; F=${3:-10000}
+  # (gpurun MERGES gpurun_out/ back: a directory name used twice would hold both runs' CSVs and the summary would count launches twice --
+  # so on the CPU side, delete gpurun_out/prof_<tag>_<workload> before a second run under the same tag)
   O=$R/gpurun_out/prof_${TAG}_$W; rm -rf $O; mkdir -p $O
   cd /tmp && export TMPDIR=/tmp
   ARGS="$R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $W --files $F"
@@ -95,6 +97,8 @@ refresh)
   bash $R/tools/gpu.sh prof $TAG text 10000 > $R/gpurun_out/prof_${TAG}_text.log 2>&1 && \
   cd $R && for w in random text; do cp gpurun_out/prof_${TAG}_$w/traffic.json gpurun_out/${TAG}_traffic_$w.json && cp gpurun_out/prof_${TAG}_$w/summary.txt gpurun_out/${TAG}_${w}_rocprofv3_summary.txt && \
     cp gpurun_out/${TAG}_traffic_$w.json profiles/traffic_$w.json; done && \
+  # (profiles/ on the GPU box is a scratch copy: bench.py below reads the fresh traffic files from it; on the CPU side copy
+  #  gpurun_out/<tag>_traffic_*.json and gpurun_out/<tag>_*_rocprofv3_summary.txt into profiles/ and commit them)
   timeout -k 10 900 python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err; rc=$?
   tail -c 300 gpurun_out/bench_${TAG}.err; grep -A12 "kernel stats" gpurun_out/${TAG}_text_rocprofv3_summary.txt | cut -c1-150
   [ $rc -eq 0 ] && bench_table gpurun_out/bench_${TAG}.json
