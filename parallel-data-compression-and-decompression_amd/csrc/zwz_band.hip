@@ -18,7 +18,7 @@
 #include "zwz_device.h"
 
 #ifndef ZWZ_BAND_EXP
-#define ZWZ_BAND_EXP 0     // timing experiments only (tools/band_exp.sh; the records are then not zlib's): 1 = no second pass, 2 = no band loop
+#define ZWZ_BAND_EXP 0     // timing experiments only (tools/gpu.sh times band ... <bits>; the records are then not zlib's): 1 = no second pass, 2 = no band loop, 4 = no record stores
 #endif
 
 // (ZWZ_BAND_EXP & 16: thread 0 of every workgroup adds the cycles it spent per phase, >> 8, to tickets[16 + phase]; launch_deflate
@@ -533,12 +533,12 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
                     if (k1) {
                         ck[i - kBand] = (uint16_t)(cntb | k1 << 8);
                         reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)(i - k1);   // the bucket field has done its work: now the link
-                        if (k1 > kShortChain) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;   // final; the second pass writes the rest
+                        if (k1 > kShortChain && !(ZWZ_BAND_EXP & 4)) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;   // final; the second pass writes the rest
                         atomicOr(&hasb[p >> 5], 1u << (p & 31u));
                     } else {
                         reinterpret_cast<uint16_t*>(S)[2u * i + 1u] = (uint16_t)kBandNoLink;
                         if (e128) {
-                            ent[p] = make_uint2(e128, e32);
+                            if (!(ZWZ_BAND_EXP & 4)) ent[p] = make_uint2(e128, e32); else asm volatile("" :: "v"(e128), "v"(e32), "v"(p));
                             atomicOr(&hasb[p >> 5], 1u << (p & 31u));
                         }
                     }
@@ -612,8 +612,11 @@ __global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8
                               kBand, i, cnt, k1, deep, L, own, e128, e32);
                 }
                 if (on) {
-                    reinterpret_cast<uint32_t*>(ent + p)[0] = e128;
-                    if (k1 <= kShortChain) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;
+                    if (ZWZ_BAND_EXP & 4) asm volatile("" :: "v"(e128), "v"(e32), "v"(p));
+                    if (!(ZWZ_BAND_EXP & 4)) {
+                        reinterpret_cast<uint32_t*>(ent + p)[0] = e128;
+                        if (k1 <= kShortChain) reinterpret_cast<uint32_t*>(ent + p)[1] = e32;
+                    }
                 }
             }
             __syncthreads();
