@@ -40,6 +40,8 @@
 // version of this measured -- and adds them, >> 8, to tickets[40 + phase] at the end; launch_deflate prints them when
 // ZWZ_MATCH_TIMES is set.  Thread 0 is in the oldest wave of its SIMD, which the SIMD favours: the other waves' share of a phase shows
 // up as its "wait".)
+// (ZWZ_MATCH_EXP & 1 / & 2: timing experiments whose records are NOT zlib's -- the window never slid; the screening pass's middle-byte gather replaced by a
+// conflict-free read -- upper bounds for round 3's two written-down ideas, measured in round 4: DESIGN.md section 8)
 #ifndef ZWZ_MATCH_EXP
 #define ZWZ_MATCH_EXP 0
 #endif
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                     okm[j] = l1[j] >= floor_[j] ? 0xffffffffu : 0u;
                     const uint32_t li = okm[j] ? l1[j] - org : wi + j;                    // a readable stand-in for positions out of play
                     l2[j] = slink[li];
-                    cb[j] = sdata[li + 1u];
+                    cb[j] = (ZWZ_MATCH_EXP & 2) ? sdata[wi + j + 65u] : sdata[li + 1u];     // (& 2, timing only: the lone candidate's middle byte without its gather)
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         const uint32_t new_org = te > kMaxDist ? (te - kMaxDist) & ~15u : 0u;
         const uint32_t delta = new_org - org;
         __syncthreads();
-        if (delta) {
+        if (delta && !(ZWZ_MATCH_EXP & 1)) {                              // (& 1, timing only: no slide -- what a ring would save at most)
             ZWZ_TILE_RANGE(t)
             (void)dlo; (void)llo;
             const uint32_t dn = dhi - (new_org >> 4), ln = lhi - (new_org >> 3);   // vectors that stay
