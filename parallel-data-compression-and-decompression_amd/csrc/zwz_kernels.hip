@@ -905,7 +905,8 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         // slide: the next tile starts at te and may look back 32506 positions
         const uint32_t new_org = te > kMaxDist ? (te - kMaxDist) & ~15u : 0u;
         const uint32_t delta = new_org - org;
-        __syncthreads();
+        // (no barrier here: the slide reads bytes and links, which the searches finished with at the barrier above; what ran since -- the has128
+        // flush -- touches s_has only, and the barriers below order it before the next tile's atomicOr.  Round 4: one of four barriers a tile.)
         if (delta && !(ZWZ_MATCH_EXP & 1)) {                              // (& 1, timing only: no slide -- what a ring would save at most)
             ZWZ_TILE_RANGE(t)
             (void)dlo; (void)llo;
