@@ -15,10 +15,18 @@ constexpr uint32_t kLinksThreads = 576;                            // one insert
 constexpr uint32_t kLinksLdsBytes = 131072 + 16 + 2 * 2048 * 4 + 512;  // 32-bit head table + spare slot + two bucket-address/link buffers + slack for read-ahead
 constexpr uint32_t kTile = 16384, kTilesPerChunk = 4;
 constexpr uint32_t kMatchThreads = 1024;
-constexpr uint32_t kMatchDataBytes = 49280;                     // bytes [tile-32506, tile+16384+266)
-constexpr uint32_t kMatchLinkBytes = 97856;                     // links [tile-32506, tile+16384)
-constexpr uint32_t kMatchListBytes = 4096 + 10240;               // bucket counts of a sorted tile / per-wave work lists of a sparse tile
-constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163520 of 163840 (with 64 static)
+// lz_match's window is a RING (round 4; rounds 1-3 slid a linear window down after every tile: two LDS passes over 147 KB and two barriers a
+// slide, a sixth of the kernel on incompressible data).  Position x lives at ring index x - (x >= kMatchRing ? kMatchRing : 0): positions are below
+// 65 536 + lookahead < 2 * kMatchRing, so the modulo is a subtract and a minimum.  The ring must hold, while tile [ts, te) is searched, the history
+// zlib may look at and the lookahead of the tile's last positions, in whole 16-byte vectors: [ts - 32 512, te + 272) = 49 168 bytes -- and a multiple
+// of 16, so that no vector and no group of four positions straddles its end.  Reads that run on from a ring index (the scan's lookahead, a
+// candidate's bytes: up to 258 + 8 of them) find the ring's first kMatchMirror bytes repeated behind its end.
+constexpr uint32_t kMatchRing = 49168, kMatchMirror = 288;
+constexpr uint32_t kMatchDataBytes = kMatchRing + kMatchMirror;  // 49 456
+constexpr uint32_t kMatchLinkBytes = 2 * kMatchRing;            // 98 336: links of the same positions (no mirror: single 16-bit reads, vectors inside a tile)
+constexpr uint32_t kMatchListBytes = 4096 + 9728;               // bucket counts of a sorted tile (8 KB) / per-wave work lists of a sparse tile (432 entries a wave)
+constexpr uint32_t kMatchLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2048 + kMatchListBytes;   // + has128 bits: 163 664 of 163 840 (with 80 static)
+static_assert(kMatchRing % 16 == 0 && kMatchRing >= 32512 + 16384 + 272 && kMatchMirror % 16 == 0 && kMatchMirror >= 258 + 8 + 16, "lz_match ring");
 constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) words of lz_sort, sorted by (bucket, position)
 constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
 constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each

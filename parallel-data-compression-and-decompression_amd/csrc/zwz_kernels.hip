@@ -40,8 +40,8 @@
 // version of this measured -- and adds them, >> 8, to tickets[40 + phase] at the end; launch_deflate prints them when
 // ZWZ_MATCH_TIMES is set.  Thread 0 is in the oldest wave of its SIMD, which the SIMD favours: the other waves' share of a phase shows
 // up as its "wait".)
-// (ZWZ_MATCH_EXP & 1 / & 2: timing experiments whose records are NOT zlib's -- the window never slid; the screening pass's middle-byte gather replaced by a
-// conflict-free read -- upper bounds for round 3's two written-down ideas, measured in round 4: DESIGN.md section 8)
+// (ZWZ_MATCH_EXP & 2: a timing experiment whose records are NOT zlib's -- the screening pass's middle-byte gather replaced by a conflict-free read: the
+// upper bound for "the inserter's middle byte in the bucket word", measured in round 4; & 1 was "no slide", the bound that led to the ring: DESIGN.md section 8)
 #ifndef ZWZ_MATCH_EXP
 #define ZWZ_MATCH_EXP 0
 #endif
@@ -494,12 +494,14 @@ __global__ __launch_bounds__(kLinksThreads) void lz_links_kernel(const uint8_t* 
 // ~13 cycles under random addresses against 2 x 10 for two ds_read_b32 (tools/exp/gather_rate.hip) -- and an alignbyte:
 // one unaligned ds_read_b32 is legal on gfx950 but is replayed in the LDS pipeline -- it doubled this kernel's time.
 // v_alignbyte_b32 looks at the low two bits of its shift operand only, so the byte address itself is the shift.)
-static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const uint16_t* link, uint32_t org, uint32_t p, uint32_t L,
+// (data / link: lz_match's rings, csrc/zwz_kernels.h; position x sits at index match_ring(x))
+static __device__ __forceinline__ uint32_t match_ring(uint32_t x) { return min(x, x - kMatchRing); }   // x < 2 * kMatchRing: x - ring wraps to a huge value below the ring's size
+static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const uint16_t* link, uint32_t p, uint32_t L,
                                                       bool active, uint32_t& e128, uint32_t& e32) {
     typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
     e128 = 0; e32 = 0;
     const uint32_t lane = lane_id();
-    const uint32_t pp = p - org;                                   // inactive lanes pass any position of the tile
+    const uint32_t pp = match_ring(p);                             // inactive lanes pass any position of the tile
     uint32_t cur = link[pp];
     const bool start = active && p + kMinMatch <= L                // lookahead < 3: not inserted, not searched
                        && cur != 0 && p - cur <= kMaxDist          // first candidate: distance <= MAX_DIST
@@ -518,8 +520,8 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
     uint32_t scan_w = scan0 & f_mask;                                             // comparisons end inside them, without a loop
     const uint32_t data_a = (uint32_t)(uintptr_t)(lds_ptr)const_cast<uint8_t*>(data);                          // LDS byte addresses
     const uint32_t link_a = (uint32_t)(uintptr_t)(lds_ptr) reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(link));
-    const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a - 2u * org);
-    uint32_t dbias = data_a - org + f_off;                         // filter word of candidate c: LDS byte cur + dbias
+    const uint32_t lbias = __builtin_amdgcn_readfirstlane(link_a);
+    uint32_t dbias = data_a + f_off;                               // filter word of candidate c: LDS byte ring(cur) + dbias (f_off <= 255: inside the mirror)
     // The walk.  A lane examines its candidates at its own pace and count (n_l): lanes whose filter word matches are PARKED --
     // they stop walking, candidate and link at hand -- and the full comparison is done for all parked lanes at once when
     // kParkLanes of them are waiting or nobody walks any more.  (Leaving the loop for every single hit -- with a wave-wide
@@ -539,10 +541,12 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
             "s_mov_b64 %[sv], exec\n\t"
             "1:\n\t"
             "s_mov_b64 exec, %[walk]\n\t"
-            "v_add_u32 %[a], %[cur], %[dbias]\n\t"
+            "v_subrev_u32 %[a], %[ring], %[cur]\n\t"            /* the candidate's ring index: min(cur, cur - ring) */
+            "v_min_u32 %[l], %[cur], %[a]\n\t"
+            "v_add_u32 %[a], %[l], %[dbias]\n\t"
             "v_and_b32 %[b], -4, %[a]\n\t"
             "ds_read2_b32 v[90:91], %[b] offset1:1\n\t"
-            "v_lshl_add_u32 %[l], %[cur], 1, %[lbias]\n\t"
+            "v_lshl_add_u32 %[l], %[l], 1, %[lbias]\n\t"
             "ds_read_u16 %[nxt], %[l]\n\t"
             "v_add_u32 %[nl], 1, %[nl]\n\t"
             "s_waitcnt lgkmcnt(1)\n\t"
@@ -567,13 +571,13 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
             : [cur] "+v"(cur), [nxt] "+v"(nxt), [nl] "+v"(n_l), [walk] "+s"(walk), [park] "+s"(park), [sv] "=&s"(sv), [cont] "=&s"(cont),
               [cnt] "=&s"(cnt), [a] "=&v"(ta), [b] "=&v"(tb), [w0] "=&v"(w0), [l] "=&v"(tl)
             : [dbias] "v"(dbias), [lbias] "s"(lbias), [fmask] "v"(f_mask), [scan] "v"(scan_w), [limit] "v"(limit), [bound] "s"(kMaxChain),
-              [npark] "s"(kParkLanes)
+              [npark] "s"(kParkLanes), [ring] "s"(kMatchRing)
             : "vcc", "scc", "memory", "v90", "v91");
         if (park == 0) break;                                      // nobody hit, nobody walks
         bool resume = false;
         if ((park >> lane) & 1ull) {                               // cur = the candidate whose filter word matched, nxt = its link, n_l counts it
             if (n_l > kShortChain && snap == kNone) snap = best >= kMinMatch ? entry_pack(best, p - best_pos) : 0u;   // what zlib's short chain returned
-            const uint32_t c_ = cur - org;
+            const uint32_t c_ = match_ring(cur);
             uint32_t x0 = load_u32(data, c_) ^ scan0, x1 = load_u32(data, c_ + 4u) ^ scan1;
             asm volatile("" : "+v"(x0), "+v"(x1));   /* both words now: left alone, the second read is sunk behind a branch on the first */
             const uint32_t l0 = (uint32_t)__builtin_ctz(x0 | 0x80000000u) >> 3, l1 = 4u + ((uint32_t)__builtin_ctz(x1 | 0x80000000u) >> 3);
@@ -584,7 +588,7 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
             if (len > best) {
                 best = len; best_pos = cur;
                 if (len >= nice) resume = false;
-                else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a - org + f_off; }
+                else { f_off = best - 3u; f_mask = 0xffffffffu; scan_w = load_u32(data, pp + f_off); dbias = data_a + f_off; }
             }
             cur = nxt;
         }
@@ -602,10 +606,11 @@ static __device__ __forceinline__ void lz_search_wave(const uint8_t* data, const
 // ------------------------------------------------------------------------------------------------
 // lz_match: per-position match records.  One workgroup walks one chunk tile by tile (16 Ki positions
 // per tile) with the history zlib may look at -- bytes and links of the last 32506 positions --
-// resident in LDS.  Between tiles the window is slid inside LDS and only the next tile's own
-// 16 KiB of bytes + 32 KiB of links come from HBM, fetched into registers while the current tile
-// is being searched (a tile-per-workgroup version re-read the whole 147 KB window per tile and
-// spent 58% of its wave-cycles waiting on it).
+// resident in LDS, as a ring (csrc/zwz_kernels.h: kMatchRing): only the next tile's own 16 KiB of
+// bytes + 32 KiB of links come from HBM, fetched into registers while the current tile is being
+// searched, and they go where the oldest tile's were (a tile-per-workgroup version re-read the whole
+// 147 KB window per tile and spent 58% of its wave-cycles waiting on it; rounds 1-3 slid a linear
+// window down after every tile).
 __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, const uint16_t* __restrict__ links,
                                                                  uint2* __restrict__ entries, uint64_t* __restrict__ has128,
@@ -652,7 +657,6 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     // data (random bytes: 57 %) the screening pass; lz_links counted while it wrote the links out
     const bool sorted_order = band == 0u && chunk_is_dense(link_stat[chunk], L);  // workgroup-uniform (with the band kernels about, what gets here is sparse)
     for (uint32_t i = tid; i < 512u; i += kMatchThreads) s_has[i] = 0;   // has128 bits of a tile (32-bit words); cleared again as they are written out
-    uint32_t org = 0;
 #if ZWZ_MATCH_EXP & 16
     uint64_t stamp_ = __builtin_amdgcn_s_memtime();
     uint32_t acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -660,12 +664,17 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
     ZWZ_PREFETCH(0u)
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint32_t ts = t * kTile, te = min(ts + kTile, L);
-        {   // registers -> LDS window whose first byte is position org
+        {   // registers -> the rings (vector v of the chunk's bytes at ring vector v mod kMatchRing / 16; the ring's first vectors repeated behind its end)
             ZWZ_TILE_RANGE(t)
-            if (dlo + tid < dhi) sd4[dlo + tid - (org >> 4)] = pd0;
-            if (dlo + tid + kMatchThreads < dhi) sd4[dlo + tid + kMatchThreads - (org >> 4)] = pd1;
-            if (llo + tid < lhi) sl4[llo + tid - (org >> 3)] = pl0;
-            if (llo + tid + kMatchThreads < lhi) sl4[llo + tid + kMatchThreads - (org >> 3)] = pl1;
+            auto put_d = [&](uint32_t v, const uint4& x) {
+                const uint32_t rv = min(v, v - kMatchRing / 16u);
+                sd4[rv] = x;
+                if (rv < kMatchMirror / 16u) sd4[kMatchRing / 16u + rv] = x;
+            };
+            if (dlo + tid < dhi) put_d(dlo + tid, pd0);
+            if (dlo + tid + kMatchThreads < dhi) put_d(dlo + tid + kMatchThreads, pd1);
+            if (llo + tid < lhi) { const uint32_t u = llo + tid; sl4[min(u, u - kMatchRing / 8u)] = pl0; }
+            if (llo + tid + kMatchThreads < lhi) { const uint32_t u = llo + tid + kMatchThreads; sl4[min(u, u - kMatchRing / 8u)] = pl1; }
         }
         __syncthreads();
         ZWZ_MSTAMP(t ? 6 : 0);                      // waiting for the tile's bytes and links, registers -> LDS (first tile: nothing hides the load)
@@ -694,9 +703,9 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 for (uint32_t j = 0; j < 4; j++) {
                     p[j] = ts + q0 + j * kMatchThreads;
                     const bool ok = p[j] < te && p[j] + kMinMatch <= L;
-                    const uint32_t l1 = slink[ok ? p[j] - org : 0u];
+                    const uint32_t l1 = slink[ok ? match_ring(p[j]) : 0u];
                     live[j] = (uint32_t)(ok && l1 != 0 && p[j] - l1 <= kMaxDist && !(p[j] >= kSlidePos && l1 <= kWSize));
-                    cur[j] = live[j] ? l1 : (ok ? p[j] : org);         // (out of play: any readable position)
+                    cur[j] = live[j] ? l1 : (ok ? p[j] : 0u);          // (out of play: any readable position)
                     cnt[j] = live[j];
                     lim[j] = p[j] > kMaxDist ? p[j] - kMaxDist : 0u;
                 }
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 for (uint32_t st = 1; st < kKeyDepth; st++) {
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t nx = slink[cur[j] - org];
+                        const uint32_t nx = slink[match_ring(cur[j])];
                         const uint32_t adv = live[j] & (uint32_t)(nx > lim[j]);
                         cur[j] = adv ? nx : cur[j]; cnt[j] += adv; live[j] = adv;
                     }
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         }
         auto search_and_store = [&](uint32_t p, bool active) {
             uint32_t e128 = 0, e32 = 0;
-            lz_search_wave(sdata, slink, org, p, L, active, e128, e32);
+            lz_search_wave(sdata, slink, p, L, active, e128, e32);
             if (e128) {
                 ent[p] = make_uint2(e128, e32);   // e128 == 0 implies e32 == 0; readers gate on has128
                 atomicOr(&s_has[(p - ts) >> 5], 1u << (p & 31u));
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
             //   anything else                      -> onto the wave's work list in LDS,
             // and then runs the full search over the list, 64 entries a trip.  The list is bounded
             // (kListCap entries): it is drained early whenever the next four trips might not fit.
-            constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 448
+            constexpr uint32_t kListCap = kMatchListBytes / 2u / (kMatchThreads / 64u);      // 432
             uint16_t* wl = s_cnt + wave * kListCap;
             uint32_t nl = 0;                                                               // wave-uniform
             auto drain = [&](bool all) {                                 // all: the tile is over; else whole trips only, the rest waits
@@ -819,14 +828,14 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 uint32_t ns = 0;
                 for (uint32_t i = lane; i - lane < n_proc; i += 64u) {
                     const bool valid = i < n_proc;
-                    const uint32_t q = valid ? (uint32_t)wl[i] : 0u, p = ts + q, pi = p - org;
+                    const uint32_t q = valid ? (uint32_t)wl[i] : 0u, p = ts + q, pi = match_ring(p);
                     const uint32_t floor1 = max(p + 1u, kMaxDist + 1u) - kMaxDist;               // a link >= this is a candidate in range
                     const uint32_t scan = sdata[pi + 1u];                                         // (one byte again: see the screening pass)
                     const uint32_t l1 = slink[pi];
-                    const uint32_t li1 = valid ? l1 - org : pi;                                   // listed: its first candidate is in range
+                    const uint32_t li1 = valid ? match_ring(l1) : pi;                             // listed: its first candidate is in range
                     const uint32_t l2 = slink[li1], cw1 = sdata[li1 + 1u];
                     const bool in2 = l2 >= floor1;
-                    const uint32_t li2 = in2 ? l2 - org : pi;
+                    const uint32_t li2 = in2 ? match_ring(l2) : pi;
                     const uint32_t l3 = slink[li2], cw2 = sdata[li2 + 1u];
                     uint32_t v = l3 >= floor1 ? scan : cw2;
                     v = in2 ? v : cw1;
@@ -855,7 +864,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
                 const uint32_t qb = t4 * 4096u + wave * 256u;                              // wave-uniform; the waves interleave: later positions have more history
                 if (qb >= n_ok) break;
                 if (nl + 256u > kListCap) drain(false);
-                const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = p0 - org;            // wi: window index, a multiple of 4
+                const uint32_t q0 = qb + lane * 4u, p0 = ts + q0, wi = match_ring(p0);      // wi: ring index, a multiple of 4 (the ring's size is one of 16: the four positions do not straddle its end)
                 const uint2 lk2 = *reinterpret_cast<const uint2*>(slink + wi);
                 const uint32_t w0 = reinterpret_cast<const uint32_t*>(sdata + wi)[0], w1 = reinterpret_cast<const uint32_t*>(sdata + wi)[1];
                 uint32_t l1[4] = {lk2.x & 0xffffu, lk2.x >> 16, lk2.y & 0xffffu, lk2.y >> 16};
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     okm[j] = l1[j] >= floor_[j] ? 0xffffffffu : 0u;
-                    const uint32_t li = okm[j] ? l1[j] - org : wi + j;                    // a readable stand-in for positions out of play
+                    const uint32_t li = okm[j] ? match_ring(l1[j]) : wi + j;              // a readable stand-in for positions out of play
                     l2[j] = slink[li];
                     cb[j] = (ZWZ_MATCH_EXP & 2) ? sdata[wi + j + 65u] : sdata[li + 1u];     // (& 2, timing only: the lone candidate's middle byte without its gather)
                 }
@@ -902,29 +911,8 @@ __global__ __launch_bounds__(kMatchThreads) void lz_match_kernel(const uint8_t* 
         }
         if (t + 1 == ntiles) break;
 
-        // slide: the next tile starts at te and may look back 32506 positions
-        const uint32_t new_org = te > kMaxDist ? (te - kMaxDist) & ~15u : 0u;
-        const uint32_t delta = new_org - org;
-        // (no barrier here: the slide reads bytes and links, which the searches finished with at the barrier above; what ran since -- the has128
-        // flush -- touches s_has only, and the barriers below order it before the next tile's atomicOr.  Round 4: one of four barriers a tile.)
-        if (delta && !(ZWZ_MATCH_EXP & 1)) {                              // (& 1, timing only: no slide -- what a ring would save at most)
-            ZWZ_TILE_RANGE(t)
-            (void)dlo; (void)llo;
-            const uint32_t dn = dhi - (new_org >> 4), ln = lhi - (new_org >> 3);   // vectors that stay
-            const uint32_t dsh = delta >> 4, lsh = delta >> 3;
-            uint4 rd[4] = {z4, z4, z4, z4}, rl[6] = {z4, z4, z4, z4, z4, z4};
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) rd[u] = sd4[i + dsh]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) rl[u] = sl4[i + lsh]; }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < dn) sd4[i] = rd[u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 6; u++) { const uint32_t i = tid + u * kMatchThreads; if (i < ln) sl4[i] = rl[u]; }
-            org = new_org;
-        }
-        ZWZ_MSTAMP(5);                              // has128 out, the slide
+        // (no slide: the next tile's bytes and links go where the oldest tile's were -- at the top of the loop, behind the barrier above)
+        ZWZ_MSTAMP(5);                              // has128 out
     }
 #undef ZWZ_TILE_RANGE
 #undef ZWZ_PREFETCH
