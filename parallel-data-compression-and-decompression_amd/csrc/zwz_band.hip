@@ -294,7 +294,10 @@ static_assert(kBandOffHas + 8192 == kBandLdsBytes, "lz_match_band LDS layout");
 static_assert(kBandTile % 64 == 0 && kBandOffE % 8 == 0 && kBandOffS % 16 == 0 && kBandOffCk % 16 == 0, "lz_match_band LDS alignment");
 constexpr uint32_t kBandRuns = kBandTile / 8;
 
-__global__ __launch_bounds__(kBandThreads) void lz_match_band_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+#ifndef ZWZ_BAND_WAVES
+#define ZWZ_BAND_WAVES 4
+#endif
+__global__ __launch_bounds__(kBandThreads, ZWZ_BAND_WAVES) void lz_match_band_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                     const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ list,
                                                                     uint32_t* __restrict__ tickets, const uint32_t* __restrict__ sorted,
                                                                     uint2* __restrict__ entries, uint64_t* __restrict__ has128) {

@@ -31,7 +31,10 @@ constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) w
 constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
 constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each
 constexpr uint32_t kBandThreads = 1024;
-constexpr uint32_t kBandTile = 5632;                             // sorted entries per tile of lz_match_band (88 groups of 64)
+#ifndef ZWZ_BAND_TILE
+#define ZWZ_BAND_TILE 5632
+#endif
+constexpr uint32_t kBandTile = ZWZ_BAND_TILE;                    // sorted entries per tile of lz_match_band (88 groups of 64)
 constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 154 176
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
