@@ -2214,7 +2214,7 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
                         }
                     }
                     const uint64_t far = __ballot(in && !lit && src + 1u > fenced);
-                    if (far) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = bstart; }
+                    if (far && !(ZWZ_INF_EXP & 2)) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_s_waitcnt(0); fenced = bstart; }   // (& 2: timing only -- what the wait for the previous rounds' stores costs; the output is then wrong now and then)
                     // back-references read bytes this CU stored a moment ago: agent-scope (sc1) loads are served
                     // by L2 and cannot hit a stale L1 line that was cached before the store
                     if (in) dst[pos] = lit ? (uint8_t)ov : __hip_atomic_load(&dst[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
