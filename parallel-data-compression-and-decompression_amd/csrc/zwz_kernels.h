@@ -32,10 +32,12 @@ constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 
 constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each
 constexpr uint32_t kBandThreads = 1024;
 #ifndef ZWZ_BAND_TILE
-#define ZWZ_BAND_TILE 5632
+#define ZWZ_BAND_TILE 6016
 #endif
-constexpr uint32_t kBandTile = ZWZ_BAND_TILE;                    // sorted entries per tile of lz_match_band (88 groups of 64)
-constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 154 176
+// sorted entries per tile of lz_match_band: 94 groups of 64 -- a full chunk's 65 533 entries are ELEVEN tiles (5 632, rounds 3-4a: twelve; the per-tile
+// phases and the 128-entry halo are paid per tile: text match stage 70.2 -> 68.3 ms; 5 120: 70.9 ms; ten tiles would need 167 KB of LDS)
+constexpr uint32_t kBandTile = ZWZ_BAND_TILE;
+constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 159 552 at 6 016
 constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords

@@ -80,7 +80,7 @@ def test_banded_search_gives_lz_search_records(emu, kind):
             continue
         data = corpus.make(kind, 5000 + i, n)
         want = _records(emu, data)
-        for tile, fmt in ((5632, -1), (5632, 0), (192, -1), (64, 0)):
+        for tile, fmt in ((6016, -1), (6016, 0), (5632, -1), (192, -1), (64, 0)):
             if tile < 1000 and n > 20000:
                 continue
             got = _band(emu, data, tile, fmt)
@@ -104,7 +104,7 @@ def test_banded_search_corners(emu):
     cases.append(bytes(corpus.text_like(78, 30000)) + corpus.random_bytes(79, 20000) + bytes(15535))
     for idx, data in enumerate(cases):
         want = _records(emu, data)
-        for tile, fmt in ((5632, -1), (5632, 0), (1024, -1)):
+        for tile, fmt in ((6016, -1), (6016, 0), (5632, 0), (1024, -1)):
             got = _band(emu, data, tile, fmt)
             assert got[0] == want[0] and got[1] == want[1], (idx, tile, fmt)
 

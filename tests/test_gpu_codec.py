@@ -50,7 +50,7 @@ def test_deflate_match_flavours_agree_with_oracle(zwz, oracle, flavour):
     8-byte words start at the trigram), chain-heavy ones through the walk."""
     codec = zwz.Codec(0, 1024)
     codec.set_option("match", flavour)
-    sizes = [0, 1, 2, 3, 4, 11, 12, 13, 64, 65, 300, 4097, 5632, 5634, 5635, 11266, 20000, 32506, 32507, 40000, 65274, 65284, 65535]
+    sizes = [0, 1, 2, 3, 4, 11, 12, 13, 64, 65, 300, 4097, 5632, 5634, 5635, 6016, 6018, 6019, 11266, 12034, 12035, 20000, 32506, 32507, 40000, 60162, 60163, 65274, 65284, 65535]
     for kind in corpus.KINDS:
         chunks = [corpus.make(kind, 8100 + i, n) for i, n in enumerate(sizes) if not (kind == "lz" and 20000 < n < 65535)]
         got = codec.deflate_chunks(chunks)
@@ -98,7 +98,7 @@ def test_plan_stage_skewed_histograms(zwz, oracle, mode):
 
 def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle):
     """Every chunk through lz_sort + lz_place + lz_match_band (option match=band), on what the production choice would never send there
-    and on what strains its corners: random lengths around the tile size (5 632 sorted entries) and its multiples; alphabets
+    and on what strains its corners: random lengths around the tile size (6 016 sorted entries; 5 632 until round 4) and its multiples; alphabets
     whose trigrams collide in zlib's 15-bit hash (mixed buckets: the 8-byte words start at the trigram) with long repeats on top
     (every entry flagged, sharers' chains through every halo); short periods; runs; chunks stitched from different kinds (the
     word format changes from tile to tile)."""
@@ -108,7 +108,7 @@ def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle):
     kinds = [k for k in corpus.KINDS if k != "lz"]
     chunks = []
     for i in range(60):
-        n = [5632, 5633, 5634, 5635, 5636, 11264, 11266, 11267, 16898, 61954, 61955][i % 11] + int(rs[4 * i] % 3) if i % 2 else int(rs[4 * i] % 65536)
+        n = [6016, 6017, 6018, 6019, 6020, 12032, 12034, 12035, 18050, 60162, 60163, 5634, 11266][i % 13] + int(rs[4 * i] % 3) if i % 2 else int(rs[4 * i] % 65536)
         chunks.append(corpus.make(kinds[int(rs[4 * i + 1] % len(kinds))], 41000 + i, min(n, 65535)))
     for i in range(60, 90):                      # bytes 0x00 / 0x20 / 0x40 / 0x60 ... in the first two trigram bytes collide in the hash's upper bits
         n = 20000 + int(rs[4 * i] % 45536)
