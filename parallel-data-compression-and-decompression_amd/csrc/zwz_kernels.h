@@ -38,13 +38,22 @@ constexpr uint32_t kBandThreads = 1024;
 // phases and the 128-entry halo are paid per tile: text match stage 70.2 -> 68.3 ms; 5 120: 70.9 ms; ten tiles would need 167 KB of LDS)
 constexpr uint32_t kBandTile = ZWZ_BAND_TILE;
 constexpr uint32_t kBandLdsBytes = (65536 + 64) + (kBandTile + 128) * 12 + kBandTile * 2 + 8192;   // bytes, words + 8-byte comparison words, counts, has128 bits: 159 552 at 6 016
-constexpr uint32_t kParseThreads = 256;                          // 4 chunks per workgroup
+// lz_parse and inflate give a chunk to a WAVE; a workgroup of one wave frees its LDS and its slot the moment that chunk is done, where four waves a
+// workgroup (rounds 1-4a) waited for their slowest: lz_parse 15.3 -> 13.7 ms on text, 6.8 -> 6.0 ms per 100 000 small files; inflate 23.4 -> 22.8 / 13.0 -> 12.7
+// (128 threads: no change either way)
+#ifndef ZWZ_PARSE_THREADS
+#define ZWZ_PARSE_THREADS 64
+#endif
+constexpr uint32_t kParseThreads = ZWZ_PARSE_THREADS;            // chunks per workgroup = threads / 64
 constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
 constexpr uint32_t kEncQueue = 128;                               // entries of a wave's queue of symbol starts (a power of two >= 127)
 constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + (kEncodeThreads / 64) * kEncQueue * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 78 528 bytes: two workgroups per CU (with __launch_bounds__(1024, 8): 64 registers)
-constexpr uint32_t kInflateThreads = 256;                       // 4 chunks per workgroup
+#ifndef ZWZ_INFLATE_THREADS
+#define ZWZ_INFLATE_THREADS 64
+#endif
+constexpr uint32_t kInflateThreads = ZWZ_INFLATE_THREADS;       // chunks per workgroup = threads / 64
 constexpr int kNumDeflateStages = 6;
 
 struct ChunkInfo { uint32_t n_sym, n_blocks; };
