@@ -1729,8 +1729,11 @@ __device__ unsigned long long g_inf_times[8];
 #define ZWZ_INF_WAVES 5
 #endif
 constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;
-constexpr uint32_t kInfRing = 2048, kInfFill = 1024, kInfMirror = 48;   // ring, refill step, bytes of the ring's start repeated behind its end (a window fetch reads 36 consecutive bytes)
-constexpr uint32_t kWinSlots = 4;          // bit offsets decoded per lane per window: 256 bits
+#ifndef ZWZ_WIN_SLOTS
+#define ZWZ_WIN_SLOTS 4
+#endif
+constexpr uint32_t kInfRing = 2048, kInfFill = 1024, kInfMirror = ((8u * ZWZ_WIN_SLOTS + 4u + 15u) / 16u) * 16u;   // ring, refill step, bytes of the ring's start repeated behind its end (a window fetch reads 36 consecutive bytes)
+constexpr uint32_t kWinSlots = ZWZ_WIN_SLOTS;   // bit offsets decoded per lane per window: 256 bits
 #ifndef ZWZ_WIN_PARTS
 #define ZWZ_WIN_PARTS 2
 #endif
@@ -2008,7 +2011,7 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
                 uint32_t at = 0;                                              // wave-uniform: the orbit's current offset from bp; kOrbitEnd once it has stopped
                 constexpr uint32_t kOrbitEnd = 0xffffu;
 #pragma unroll 1
-              for (uint32_t wb = 0; wb < 256u * kWinParts; wb += 256u) {      // wb: this window's first offset
+              for (uint32_t wb = 0; wb < 64u * kWinSlots * kWinParts; wb += 64u * kWinSlots) {      // wb: this window's first offset
                 // A slot says only what KIND of symbol would start at its bit and how many bits it would take: two table lookups on
                 // packed entries (inflate_core.h), no arithmetic on lengths or distances -- 93 % of the slots are not symbols.  The
                 // values are decoded once per round, by lane i for symbol i, in the pass behind the orbit.  (Round 3 decoded every
