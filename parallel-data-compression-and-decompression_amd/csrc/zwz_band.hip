@@ -105,6 +105,12 @@ __global__ __launch_bounds__(1024) void lz_lists_kernel(const uint32_t* __restri
 // ------------------------------------------------------------------------------------------------
 // lz_sort.  The table holds two 16-bit counters a dword (bucket h in half h & 1 of dword h >> 1): 64 KiB, two workgroups a CU.
 // A counter never carries into its neighbour: it ends at bucket start + bucket size <= 65 533.
+// returning adds the ranking wave keeps in flight (a trip's worth): the step is the LDS's LATENCY for a returning atomic divided by what is in flight, and the
+// kernel's two workgroups a CU leave a wave 256 registers -- 4: 7.81 ms for the links stage on text, 8 (round 3): 7.33, 16: 7.00, 24: 6.93
+#ifndef ZWZ_SORT_DEPTH
+#define ZWZ_SORT_DEPTH 16
+#endif
+constexpr uint32_t kSortDepth = ZWZ_SORT_DEPTH;
 __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ list,
                                                                uint32_t* __restrict__ tickets, uint32_t* __restrict__ sorted,
@@ -194,39 +200,40 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         if (wave == 0) {
             // Whole trips of eight steps run without a single test (every lane has a position: guarded per lane, the loop was
             // mostly exec-mask bookkeeping); the next trip's hashes are on their way while this one ranks.
-            const uint32_t full = n >> 9;                                       // trips of 512 positions
+            constexpr uint32_t K = kSortDepth;                                      // steps a trip: that many returning adds in flight
+            const uint32_t full = n / (64u * K);                                   // trips of 64 K positions
             // (running pointers, so that a trip's eight loads and eight stores are one address and constant offsets; hb holds byte
             // offset | half, see the histogram: per step the wave is left with and + two shifts + the add, and a shift + the store)
             auto bump = [&](uint32_t w) { return atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(tab) + (w & 0xfffcu)), 1u << ((w & 1u) << 4)); };
             const uint16_t* hin = hb + lane;
             uint16_t* o = out + lane;
-            uint32_t hv[8];
+            uint32_t hv[K];
             auto ask = [&](uint32_t* h8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) h8[j] = hin[j * 64u];
-                hin += 512;
+                for (uint32_t j = 0; j < K; j++) h8[j] = hin[j * 64u];
+                hin += 64u * K;
             };
             if (full) ask(hv);
-            uint32_t hp[8], op[8];                                              // the previous trip's entries and what its adds returned
+            uint32_t hp[K], op[K];                                              // the previous trip's entries and what its adds returned
             for (uint32_t t = 0; t < full; t++) {
-                uint32_t hn[8], old[8];
+                uint32_t hn[K], old[K];
                 if (t + 1u < full) ask(hn);
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) old[j] = bump(hv[j]);
+                for (uint32_t j = 0; j < K; j++) old[j] = bump(hv[j]);
                 // (the previous trip's results are written out while this trip's adds are on their way through the LDS)
                 if (t) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
-                    o += 512;
+                    for (uint32_t j = 0; j < K; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                    o += 64u * K;
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) { hp[j] = hv[j]; op[j] = old[j]; hv[j] = hn[j]; }
+                for (uint32_t j = 0; j < K; j++) { hp[j] = hv[j]; op[j] = old[j]; hv[j] = hn[j]; }
             }
             if (full) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
+                for (uint32_t j = 0; j < K; j++) o[j * 64u] = (uint16_t)(op[j] >> ((hp[j] & 1u) << 4));
             }
-            for (uint32_t p = full * 512u + lane; p - lane < n; p += 64u) {     // the ragged end, a step at a time
+            for (uint32_t p = full * 64u * K + lane; p - lane < n; p += 64u) {  // the ragged end, a step at a time
                 if (p < n) {
                     const uint32_t w = hb[p];
                     out[p] = (uint16_t)(bump(w) >> ((w & 1u) << 4));
