@@ -273,7 +273,8 @@ int zwz_ctx_set_option(zwz_ctx* c, const char* name, const char* value) {
     if (!c || !name || !value) return ZWZ_E_INVALID;
     const std::string n = name, v = value;
     if (n == "match") {
-        if (v == "auto" || v.empty()) c->match_mode = kMatchAuto; else if (v == "walk") c->match_mode = kMatchWalk; else if (v == "band") c->match_mode = kMatchBand; else return ZWZ_E_INVALID;
+        if (v == "auto" || v.empty()) c->match_mode = kMatchAuto; else if (v == "walk") c->match_mode = kMatchWalk; else if (v == "band") c->match_mode = kMatchBand; else if (v == "lazy") c->match_mode = kMatchLazy;
+        else if (v == "autoband") c->match_mode = kMatchAutoBand; else if (v == "autolazy") c->match_mode = kMatchAutoLazy; else return ZWZ_E_INVALID;
     } else if (n == "plan") {
         if (v == "wave" || v.empty()) c->plan_serial = 0; else if (v == "serial") c->plan_serial = 1; else return ZWZ_E_INVALID;
     } else if (n == "inflate_header") {

@@ -30,6 +30,12 @@ static_assert(kMatchRing % 16 == 0 && kMatchRing >= 32512 + 16384 + 272 && kMatc
 constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) words of lz_sort, sorted by (bucket, position)
 constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
 constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each
+// lz_lazy (zwz_lazy.hip): a lane per 128-position segment of the chunk.  Its scratch is the chunk's entries space (which the band would
+// fill): the step memo of every position, G (fresh-search marks of lanes beyond their segment), and -- written by lz_sort -- the ends of
+// the 32 768 buckets in the sorted array (16 bits each).
+constexpr uint32_t kLazyThreads = 512, kLazySeg = 128;
+constexpr uint32_t kLazyScratchWords = 2 * kEntryStride, kLazyStepOff = 0, kLazyMarkOff = 65536, kLazyBendOff = 65536 + 2048;   // 32-bit words
+static_assert(kLazyBendOff + 16384 <= kLazyScratchWords, "lz_lazy scratch fits the entries space");
 constexpr uint32_t kBandThreads = 1024;
 #ifndef ZWZ_BAND_TILE
 #define ZWZ_BAND_TILE 6016
@@ -121,13 +127,19 @@ struct InflateArgs {
     uint4* order;              // n entries of scratch (the launch fills it: (offset, length, chunk) by payload length, longest first), or null: as they come
     uint32_t serial_header;    // 1: block headers and tables by lane 0 alone (inflate_block_rest) -- no ordered LDS adds
 };
-enum : uint32_t { kMatchAuto = 0, kMatchWalk = 1, kMatchBand = 2 };
+// match_mode: auto = lz_dense_list decides per chunk between links + lz_match (+ lz_parse) and sort + lz_lazy; walk / band / lazy = every chunk through
+// that search; autoband / autolazy = the per-chunk choice with the band + lz_parse / lz_lazy for the chain-heavy ones.  Same bytes whichever runs.
+enum : uint32_t { kMatchAuto = 0, kMatchWalk = 1, kMatchBand = 2, kMatchLazy = 3, kMatchAutoBand = 4, kMatchAutoLazy = 5 };
+#ifndef ZWZ_AUTO_LAZY
+#define ZWZ_AUTO_LAZY 0
+#endif
+constexpr bool kAutoIsLazy = ZWZ_AUTO_LAZY != 0;      // what "auto" sends chain-heavy chunks through: lz_lazy, or the band + lz_parse
 // Experiment defines this library was built with (all zero in the product; tools/gpu.sh times builds libzwz_hip_exp.so with one set)
 uint32_t exp_flags_kernels();   // ZWZ_MATCH_EXP | ZWZ_PARSE_EXP << 8 | ZWZ_ENC_EXP << 16 | ZWZ_INF_EXP << 24
 uint32_t exp_flags_band();      // ZWZ_BAND_EXP
 
 constexpr size_t kTicketBytes = 256;
-enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7 };   // indices into DeflateArgs::tickets
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7, kTicketLazyNext = 8 };   // indices into DeflateArgs::tickets
 // lz_match on its own (ZWZ_MATCH=walk): a chunk four of whose five positions have a chain predecessor (lz_links' count) takes the sorted walk.
 __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
 // With the band kernels: lz_dense_list looks at a chunk's first kDenseSample positions and calls it chain-heavy -- sort + band --
@@ -149,6 +161,9 @@ hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which
 hipError_t launch_sort(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_place(const DeflateArgs& a, hipStream_t s);
 hipError_t launch_match_band(const DeflateArgs& a, hipStream_t s);
+hipError_t configure_lazy_kernels();                                                     // zwz_lazy.hip
+hipError_t launch_lazy(const DeflateArgs& a, hipStream_t s);
+uint32_t exp_flags_lazy();
 hipError_t launch_plan(const DeflateArgs& a, hipStream_t s);                             // zwz_plan.hip
 hipError_t launch_inflate(const InflateArgs& a, hipStream_t s);
 hipError_t launch_md5_files(const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, const uint32_t* files, uint32_t n_files,

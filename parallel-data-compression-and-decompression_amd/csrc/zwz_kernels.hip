@@ -950,10 +950,12 @@ struct ParseWaveMem {
 __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t* __restrict__ in_len, uint32_t n,
                                                                 const uint2* __restrict__ entries, const uint64_t* __restrict__ has128,
                                                                 uint64_t* __restrict__ sym, uint64_t* __restrict__ mst,
-                                                                ChunkInfo* __restrict__ info, uint16_t* __restrict__ links) {
+                                                                ChunkInfo* __restrict__ info, uint16_t* __restrict__ links,
+                                                                const uint32_t* __restrict__ parsed_marks /* link_stat: kDenseMark = lz_lazy has parsed this chunk; or null */) {
     __shared__ ParseWaveMem s_mem[kParseThreads / 64];
     const uint32_t chunk = blockIdx.x * (kParseThreads / 64) + (threadIdx.x >> 6);
     if (chunk >= n) return;
+    if (parsed_marks && parsed_marks[chunk] == kDenseMark) return;
     ParseWaveMem& m = s_mem[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     const uint2* ent = entries + (size_t)chunk * kEntryStride;
@@ -2390,6 +2392,7 @@ hipError_t configure_kernels() {
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(exchange_order_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
+    ZWZ_TRY(configure_lazy_kernels());
     return configure_band_kernels();
 }
 
@@ -2401,18 +2404,20 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     // search (zwz_band.hip).  The rest: chain links, then lz_match's screening pass over them.  ZWZ_MATCH=walk sends every chunk
     // through links + lz_match (its sorted walk included), =band every chunk through the band.
     const uint32_t which = a.match_mode;         // the context's option (zwz_ctx_set_option; ZWZ_MATCH is read once, at zwz_ctx_create)
+    const bool lazy = which == kMatchLazy || which == kMatchAutoLazy || (which == kMatchAuto && kAutoIsLazy);      // chain-heavy chunks: sort + lz_lazy (search and parse in one), else sort + band + lz_parse
+    const uint32_t force = (which == kMatchBand || which == kMatchLazy) ? 2u : 0u;    // 2: every chunk counts as chain-heavy
     // (stage 0 of the profile = everything that prepares the search: marks and lists, chain links of the sparse chunks, the sorted
     // arrays of the chain-heavy ones; stage 1 = the searches themselves: lz_match, lz_match_band)
     if (which == 1u) ZWZ_TRY(launch_links(a, s, false));
     else {
-        ZWZ_TRY(launch_dense_list(a, s, which));
+        ZWZ_TRY(launch_dense_list(a, s, force));
         ZWZ_TRY(launch_links(a, s, true));
         ZWZ_TRY(launch_sort(a, s));
         ZWZ_TRY(launch_place(a, s));
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,
-                       a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : which == 2u ? 2u : 1u, a.tickets + 40);
+                       a.links, a.entries, a.has128, a.perm, a.link_stat, which == 1u ? 0u : force == 2u ? 2u : 1u, a.tickets + 40);
 #if ZWZ_MATCH_EXP & 16
     if (getenv("ZWZ_MATCH_TIMES")) {
         uint32_t h[64];
@@ -2421,7 +2426,8 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
         fprintf(stderr, "ZWZ_MATCH_TIMES n=%u stage0=%u stage=%u screen=%u refine=%u search=%u wait=%u flush_slide=%u\n", a.n, h[40], h[46], h[41], h[42], h[43], h[44], h[45]);
     }
 #endif
-    if (which != 1u) {
+    if (which != 1u && lazy) ZWZ_TRY(launch_lazy(a, s));
+    if (which != 1u && !lazy) {
         ZWZ_TRY(launch_match_band(a, s));
         if ((exp_flags_band() & 16u) && getenv("ZWZ_BAND_TIMES")) {       // experiment builds (zwz_band.hip, ZWZ_BAND_EXP & 16): cycles >> 8 per phase, summed over the workgroups' first threads
             uint32_t h[64];
@@ -2431,7 +2437,8 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
         }
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((a.n + kParseThreads / 64 - 1) / (kParseThreads / 64)), dim3(kParseThreads), 0, s, a.in_len, a.n, a.entries, a.has128, a.sym, a.mst, a.info, a.links,
+                       (which != 1u && lazy) ? a.link_stat : (const uint32_t*)nullptr);
 #if ZWZ_PARSE_EXP & 16
     if (getenv("ZWZ_PARSE_TIMES")) {
         unsigned long long h[8], z[8] = {0};

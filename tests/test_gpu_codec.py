@@ -42,12 +42,13 @@ def test_deflate_matches_oracle(codec, oracle, kind):
         assert g == oracle.payload(c), (kind, len(c))
 
 
-@pytest.mark.parametrize("flavour", ["band", "walk"])
+@pytest.mark.parametrize("flavour", ["lazy", "band", "walk", "autoband", "autolazy"])
 def test_deflate_match_flavours_agree_with_oracle(zwz, oracle, flavour):
-    """Production picks a chunk's match kernel by its chain density (lz_sort + lz_match_band for chain-heavy chunks,
-    lz_match's screening pass for the rest).  The context's "match" option sends EVERY chunk through one of them: each must
-    give the oracle's payloads on every kind of content -- sparse chunks through the band (mixed-trigram buckets: the
-    8-byte words start at the trigram), chain-heavy ones through the walk."""
+    """Production picks a chunk's search by its chain density (lz_sort + lz_lazy -- search and lazy parse in one, the searches on
+    demand -- for chain-heavy chunks; lz_match's screening pass + lz_parse for the rest).  The context's "match" option sends EVERY
+    chunk through one of them (lazy, walk, or round 4's band + lz_parse; autoband = round 4's per-chunk choice): each must
+    give the oracle's payloads on every kind of content -- sparse chunks through lz_lazy and the band (mixed-trigram buckets),
+    chain-heavy ones through the walk."""
     codec = zwz.Codec(0, 1024)
     codec.set_option("match", flavour)
     sizes = [0, 1, 2, 3, 4, 11, 12, 13, 64, 65, 300, 4097, 5632, 5634, 5635, 6016, 6018, 6019, 11266, 12034, 12035, 20000, 32506, 32507, 40000, 60162, 60163, 65274, 65284, 65535]
@@ -96,14 +97,15 @@ def test_plan_stage_skewed_histograms(zwz, oracle, mode):
     codec.close()
 
 
-def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle):
-    """Every chunk through lz_sort + lz_place + lz_match_band (option match=band), on what the production choice would never send there
+@pytest.mark.parametrize("flavour", ["band", "lazy"])
+def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle, flavour):
+    """Every chunk through lz_sort + lz_place + lz_match_band (option match=band) / + lz_lazy (match=lazy), on what the production choice would never send there
     and on what strains its corners: random lengths around the tile size (6 016 sorted entries; 5 632 until round 4) and its multiples; alphabets
     whose trigrams collide in zlib's 15-bit hash (mixed buckets: the 8-byte words start at the trigram) with long repeats on top
     (every entry flagged, sharers' chains through every halo); short periods; runs; chunks stitched from different kinds (the
     word format changes from tile to tile)."""
     codec = zwz.Codec(0, 1024)
-    codec.set_option("match", "band")
+    codec.set_option("match", flavour)
     rs = corpus.splitmix64(90210, 4 * 160)
     kinds = [k for k in corpus.KINDS if k != "lz"]
     chunks = []

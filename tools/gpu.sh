@@ -78,7 +78,7 @@ prof)
 times)
   K=${1:-band}; W=${2:-text}; F=${3:-2000}; X=$((16 | ${4:-0}))
   case $K in band) D=ZWZ_BAND_EXP; E=ZWZ_BAND_TIMES;; match) D=ZWZ_MATCH_EXP; E=ZWZ_MATCH_TIMES;; parse) D=ZWZ_PARSE_EXP; E=ZWZ_PARSE_TIMES;;
-             enc) D=ZWZ_ENC_EXP; E=ZWZ_ENC_TIMES;; inf) D=ZWZ_INF_EXP; E=ZWZ_INF_TIMES;; *) echo "times: band|match|parse|enc|inf"; exit 2;; esac
+             enc) D=ZWZ_ENC_EXP; E=ZWZ_ENC_TIMES;; inf) D=ZWZ_INF_EXP; E=ZWZ_INF_TIMES;; lazy) D=ZWZ_LAZY_EXP; E=ZWZ_LAZY_TIMES;; *) echo "times: band|match|parse|enc|inf|lazy"; exit 2;; esac
   make -C $PKG EXP_FLAGS="-D$D=$X" libzwz_hip_exp.so > $R/gpurun_out/exp_build.log 2>&1 || { echo "experiment build failed"; tail -30 $R/gpurun_out/exp_build.log; exit 1; }
   cd $R && ZWZ_LIB=$PKG/libzwz_hip_exp.so env $E=1 timeout -k 10 400 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --workload $W --files $F 2>&1 | grep -E "$E|EXPERIMENT|stage_ms" | cut -c1-700 ;;
 variant)   # <tag> "<compiler flags>" [bench.py args ...]: a build with other constants (e.g. -DZWZ_INF_WAVES=4) as libzwz_hip_exp.so, one bench run on it
