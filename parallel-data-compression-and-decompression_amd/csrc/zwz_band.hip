@@ -114,7 +114,8 @@ constexpr uint32_t kSortDepth = ZWZ_SORT_DEPTH;
 __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ list,
                                                                uint32_t* __restrict__ tickets, uint32_t* __restrict__ sorted,
-                                                               uint16_t* __restrict__ hbuf /* the chunks' dead link arrays */) {
+                                                               uint16_t* __restrict__ hbuf /* the chunks' dead link arrays */,
+                                                               uint32_t* __restrict__ scratch /* the chunks' entries space (lz_lazy's bucket ends), or null */) {
     __shared__ __attribute__((aligned(16))) uint32_t tab[16384];
     __shared__ uint32_t s_wsum[kSortThreads / 64];
     __shared__ uint32_t s_chunk;
@@ -239,6 +240,13 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
                     out[p] = (uint16_t)(bump(w) >> ((w & 1u) << 4));
                 }
             }
+        }
+        // the table now holds every bucket's END in the sorted array (a counter ran from its bucket's start): lz_lazy's bucket bounds
+        if (scratch) {
+            __syncthreads();
+            uint4* o4 = reinterpret_cast<uint4*>(scratch + (size_t)chunk * kLazyScratchWords + kLazyBendOff);
+            const uint4* t4 = reinterpret_cast<const uint4*>(tab);
+            for (uint32_t i = tid; i < 4096u; i += kSortThreads) o4[i] = t4[i];
         }
     }
 }
@@ -666,7 +674,8 @@ hipError_t launch_dense_list(const DeflateArgs& a, hipStream_t s, uint32_t which
 hipError_t launch_sort(const DeflateArgs& a, hipStream_t s) {
     const uint32_t cus = a.cu_count ? a.cu_count : 256u;
     const uint32_t G = a.n < 2u * cus ? a.n : 2u * cus;
-    hipLaunchKernelGGL(lz_sort_kernel, dim3(G), dim3(kSortThreads), 0, s, a.in, a.in_off, a.in_len, a.dense_list, a.tickets, a.sorted, a.links);
+    hipLaunchKernelGGL(lz_sort_kernel, dim3(G), dim3(kSortThreads), 0, s, a.in, a.in_off, a.in_len, a.dense_list, a.tickets, a.sorted, a.links,
+                       reinterpret_cast<uint32_t*>(a.entries));
     return hipGetLastError();
 }
 

@@ -30,11 +30,12 @@ static_assert(kMatchRing % 16 == 0 && kMatchRing >= 32512 + 16384 + 272 && kMatc
 constexpr uint32_t kSortedStride = 65536;  // uint32 (bucket << 16 | position) words of lz_sort, sorted by (bucket, position)
 constexpr uint32_t kSortThreads = 256;                           // lz_sort: 64 KiB of packed counters, two workgroups a CU
 constexpr uint32_t kPlaceThreads = 1024, kPlaceLdsBytes = 131072;  // lz_place: the chunk's sorted positions, 16 bits each
-// lz_lazy (zwz_lazy.hip): lz_match's rings, a lane per 32-position segment of the tile in them.  Its scratch is the chunk's entries space
-// (which lz_match / the band would fill): the step memo of every position, then the chunk's fresh-search marks.
-constexpr uint32_t kLazyThreads = 512, kLazySeg = 32;
-constexpr uint32_t kLazyScratchWords = 2 * kEntryStride, kLazyStepOff = 0, kLazyMarkOff = 65536;   // 32-bit words
-constexpr uint32_t kLazyLdsBytes = kMatchDataBytes + kMatchLinkBytes + 2 * (kTile / 8) + (65536 / kLazySeg) * 2;   // rings, F, G, segment ends: 155 984
+// lz_lazy (zwz_lazy.hip): a lane per 128-position segment of the chunk.  Its scratch is the chunk's entries space (which the band would
+// fill): the step memo of every position, G (fresh-search marks of lanes beyond their segment), and -- written by lz_sort -- the ends of
+// the 32 768 buckets in the sorted array (16 bits each).
+constexpr uint32_t kLazyThreads = 512, kLazySeg = 128;
+constexpr uint32_t kLazyScratchWords = 2 * kEntryStride, kLazyStepOff = 0, kLazyMarkOff = 65536, kLazyBendOff = 65536 + 2048;   // 32-bit words
+static_assert(kLazyBendOff + 16384 <= kLazyScratchWords, "lz_lazy scratch fits the entries space");
 constexpr uint32_t kBandThreads = 1024;
 #ifndef ZWZ_BAND_TILE
 #define ZWZ_BAND_TILE 6016

@@ -2412,15 +2412,8 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     else {
         ZWZ_TRY(launch_dense_list(a, s, force));
         ZWZ_TRY(launch_links(a, s, true));
-        if (lazy) {                                  // lz_lazy walks chain links too: the chain-heavy chunks' (their linked-position counts go nowhere: a.sorted is idle)
-            const uint32_t cus = a.cu_count ? a.cu_count : 256u, G = a.n < cus ? a.n : cus;
-            if ((uint64_t)a.n > 65535ull * G) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(lz_links_kernel, dim3(G), dim3(kLinksThreads), kLinksLdsBytes, s, a.in, a.in_off, a.in_len, a.links, a.sorted, a.n,
-                               a.dense_list, a.tickets + kTicketDenseCount);
-        } else {
-            ZWZ_TRY(launch_sort(a, s));
-            ZWZ_TRY(launch_place(a, s));
-        }
+        ZWZ_TRY(launch_sort(a, s));
+        ZWZ_TRY(launch_place(a, s));
     }
     if (ev) ZWZ_TRY(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lz_match_kernel, dim3(a.n), dim3(kMatchThreads), kMatchLdsBytes, s, a.in, a.in_off, a.in_len,

@@ -10,7 +10,7 @@ def load():
     so = os.path.join(HERE, "emu", "libzwz_emu.so")
     src = os.path.join(HERE, "emu", "zwz_emu.cpp")
     csrc = os.path.join(HERE, "..", "parallel-data-compression-and-decompression_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in ("lz_core.h", "lz_band.h", "huff_core.h", "zwz_common.h", "inflate_core.h")]
+    deps = [src] + [os.path.join(csrc, f) for f in ("lz_core.h", "lz_band.h", "lz_lazy.h", "huff_core.h", "zwz_common.h", "inflate_core.h")]
     deps = [d for d in deps if os.path.exists(d)]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
@@ -28,6 +28,8 @@ def load():
     lib.emu_overflow_hits.restype = ctypes.c_uint64
     lib.emu_packed_window_check.restype = ctypes.c_uint32
     lib.emu_packed_window_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.emu_lazy_check.restype = ctypes.c_uint32
+    lib.emu_lazy_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     lib.emu_parse_blocks_check.restype = ctypes.c_int
     lib.emu_parse_blocks_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
     return lib

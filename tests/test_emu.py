@@ -109,6 +109,45 @@ def test_banded_search_corners(emu):
             assert got[0] == want[0] and got[1] == want[1], (idx, tile, fmt)
 
 
+@pytest.mark.parametrize("kind", list(corpus.KINDS))
+def test_lazy_parse_on_speculative_segments_gives_the_table_walk(emu, kind):
+    """csrc/lz_lazy.h -- zlib's lazy parse with its searches on demand, lanes starting at segment heads on the assumption that nothing
+    is pending, stopping where they meet an owner's mark, the true chain of segments replayed over the marks (the lz_lazy kernel's
+    decomposition) -- against lz_core.h's records of every position + table walk: symbol starts, match starts, chosen records.  Segment
+    sizes from the kernel's (128; 32 in its ring form) down to 16, lanes advanced one after the other, last first and in random orders."""
+    import ctypes
+    st = (ctypes.c_uint64 * 4)()
+    for i, n in enumerate([0, 1, 2, 3, 4, 5, 11, 130, 300, 4097, 20000, 65274 + 7, 65535]):
+        if kind == "lz" and 20000 < n < 65535:
+            continue
+        data = corpus.make(kind, 7000 + i, n)
+        for seg, seeds in ((128, (0, 1, 2, 3)), (32, (1, 2)), (16, (3,))):
+            for seed in seeds:
+                r = emu.emu_lazy_check(data, n, seg, seed, st)
+                assert r == 0, (kind, n, seg, seed, hex(r))
+        if n == 65535 and kind == "text":
+            assert st[2] > 1000                      # most segments' owners end up on the chain of true lanes
+
+
+def test_lazy_parse_corners(emu):
+    # a first candidate at exactly MAX_DIST (allowed), at MAX_DIST once zlib's window has slid (not), position 0 as the only earlier
+    # occurrence (NIL), matches of max_lazy bytes and more (no search behind them), nice matches, matches that end with the data
+    base = bytearray(corpus.random_bytes(4242, 65535))
+    cases = []
+    a = bytearray(base); a[32506 + 100:32506 + 120] = a[100:120]; cases.append(bytes(a))
+    a = bytearray(base); a[65274:65274 + 12] = a[32768:32768 + 12]; cases.append(bytes(a))
+    a = bytearray(base); a[65275:65275 + 12] = a[32769:32769 + 12]; cases.append(bytes(a))
+    a = bytearray(base); a[5000:5040] = a[0:40]; cases.append(bytes(a))
+    a = bytearray(base); a[65535 - 40:] = a[1000:1040]; cases.append(bytes(a))
+    a = bytearray(base); a[65535 - 9:] = a[1000:1009]; a[65535 - 300:65535 - 291] = a[1000:1009]; cases.append(bytes(a))
+    cases.append(bytes(b"abcabcabd" * 7000)[:65535])
+    cases.append(corpus.text_like(77, 65535, vocab=64))
+    cases.append(bytes(corpus.text_like(78, 30000)) + corpus.random_bytes(79, 20000) + bytes(15535))
+    for idx, data in enumerate(cases):
+        for seg, seed in ((128, 1), (128, 2), (32, 3)):
+            assert emu.emu_lazy_check(data, len(data), seg, seed, None) == 0, (idx, seg, seed)
+
+
 def test_plan_split_matches_plan_block_on_histograms(emu):
     """csrc/zwz_plan.hip's decomposition of zlib's block flush (heap a lane per tree, depths by pointer jumping over the
     merges, capped lengths + overflow repair, codes by rank, code-length runs one by one) against huff_core.h's plan_block on
