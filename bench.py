@@ -7,8 +7,10 @@ all ranks (max over ranks of the timed region).  Ranks own disjoint files (shard
 section 8e): weak scaling, no data-path collective.
 
 With no --workload the run covers BOTH headline configurations and prints ONE JSON line:
-  top level   BASELINE configs[1]: 10 000 x 256 KiB incompressible files (50 000 chunks; stored-block path)
-  "text"      BASELINE configs[2]: 10 000 x 256 KiB text-like files (LZ77 + Huffman kernels), same fields
+  top level   BASELINE configs[2]: 10 000 x 256 KiB text-like files (50 000 chunks; the LZ77 + Huffman kernels) -- the line's `value`
+  "random"    BASELINE configs[1]: 10 000 x 256 KiB incompressible files (stored-block path), same fields
+  "e2e"       the drop-in CLI (`main compress` + `main decompress`) on the same two directories and on a 4x larger text one: banner seconds,
+              GB/s, steady state / fixed cost -- what a user of the reference's command line sees; never `value`
 Other workloads on request: --workload small_files (configs[3]: ~370 000 image-like files, ~2.5 GB) and
 --workload one_file --decompress-only (configs[4] scaled to fit: ONE file, its records split over the ranks).
 
@@ -61,6 +63,9 @@ def parse_args():
     ap.add_argument("--cpu-sample-small-files", type=int, default=40000, help="small_files: files of the CPU baseline's sample (~270 MB: ~6 s at 1 rank)")
     ap.add_argument("--cpu-sample-one-file-bytes", type=int, default=512 << 20, help="one_file: bytes of the CPU baseline's single file (~12 s to compress at 1 rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (the CLI `main compress|decompress` on the same directories)")
+    ap.add_argument("--e2e-scale", type=int, default=4, help="also run the text directory this many times larger (steady state visible); 0: skip")
+    ap.add_argument("--e2e-tmp", default=None, help="where the e2e directories are built (default: $ZWZ_E2E_TMP or /tmp)")
     ap.add_argument("--cpu-baseline-port", action="store_true", help="time the oracle restatement if the reference binary is absent (labelled kind=port)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks share cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
@@ -118,7 +123,7 @@ def _cpu_facts(path):
     return facts
 
 
-def _run_timed(cmd, limit_s=900):
+def _run_timed(cmd, limit_s=900, banner_file=None):
     """Run a command to its end; wall time between the spawn and the child's exit as wait() sees it (no polling: a
     subprocess.run(timeout=...) wakes every 50 ms and quantised every figure of round 2), and the interval the reference
     prints itself (main.cpp:148-155, MPI_Wtime around the operation -- what BASELINE.md section 3 asks for)."""
@@ -142,6 +147,11 @@ def _run_timed(cmd, limit_s=900):
     wall = time.perf_counter() - t0
     if rc != 0:
         raise subprocess.CalledProcessError(rc, cmd)
+    if banner_file is not None:          # several MPI ranks: rank 0's own stdout (mpiexec -outfile-pattern), where no other rank's lines cut into the banner
+        try:
+            out = open(banner_file, "rb").read()
+        except OSError:
+            pass
     m = re.findall(rb"Time Taken: ([0-9.eE+-]+) seconds", out)
     return wall, (float(m[-1]) if m else None)
 
@@ -151,8 +161,10 @@ def _time_reference(src, work, total_bytes, ranks):
     (decompression.cpp:174).  Warm page cache.  *_s is the wall clock around the whole command (process start-up, MPI
     bootstrap and the file sort included), *_banner_s the reference's own "Time Taken"; the GB/s figures use the wall clock."""
     dst, back = os.path.join(work, "zwz%d" % ranks), os.path.join(work, "back%d" % ranks)
-    cmd = [REF_MAIN] if ranks == 1 else [MPIEXEC, "-n", str(ranks), REF_MAIN]
-    tc, bc = _run_timed(cmd + ["compress", src, dst])
+    # (K ranks write one stdout: their lines used to cut into rank 0's banner and the "Time Taken" regex lost it -- every rank gets its own file)
+    pat = os.path.join(work, "ref_out_%d" % ranks)
+    cmd = [REF_MAIN] if ranks == 1 else [MPIEXEC, "-n", str(ranks), "-outfile-pattern", pat + ".%r", REF_MAIN]
+    tc, bc = _run_timed(cmd + ["compress", src, dst], banner_file=(pat + ".0") if ranks > 1 else None)
     td, bd = _run_timed([REF_MAIN, "decompress", dst, back])
     shutil.rmtree(dst, ignore_errors=True)
     shutil.rmtree(back, ignore_errors=True)
@@ -267,6 +279,28 @@ def cpu_baseline_tree(populate, sample, ks):
                 "timer": "wall clock from spawn to the child's exit; *_banner_s = the reference's own 'Time Taken' (main.cpp:148-155)", "ranks": ranks}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ end to end (the CLI)
+def e2e_legs(args):
+    """`main compress|decompress` on the two headline directories (+ the text one args.e2e_scale times larger): tools/e2e.py's measurement,
+    summarised.  Failures of this leg never lose the GPU line: they come back as a note."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    try:
+        import e2e as e2e_tool
+        if args.e2e_tmp:
+            os.environ["ZWZ_E2E_TMP"] = args.e2e_tmp
+        n = args.files or 10000
+        for nm in ("random", "text"):
+            out[nm] = e2e_tool.summarize(e2e_tool.measure(nm, n, False))
+        if args.e2e_scale and args.e2e_scale > 1:
+            out["text_x%d" % args.e2e_scale] = e2e_tool.summarize(e2e_tool.measure("text", n * args.e2e_scale, False))
+        out["note"] = ("the drop-in CLI end to end, one GPU, one process: raw bytes / the banner's seconds; steady_* = the pipelined slices alone, "
+                       "fixed_s = process + HIP start-up, context self-tests, enumeration + sort, pinning, teardown (from a second, ZWZ_TIMELINE run)")
+    except Exception as e:
+        out["note"] = "e2e leg failed: %r" % (e,)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ verification
@@ -549,7 +583,8 @@ def main():
         dist.barrier()
     codec = zwz.Codec(local, args.max_batch)
 
-    names = ["random", "text"] if args.workload == "both" else [args.workload]
+    # (both: the text-like configuration first -- it is the line's `value` -- then the incompressible one)
+    names = ["text", "random"] if args.workload == "both" else [args.workload]
     results = [run_workload(args, torch, dist, codec, dev, world, rank, nm) for nm in names]
     if rank == 0:
         head = results[0]
@@ -564,20 +599,36 @@ def main():
             line.setdefault(k, v)
         for nm, r in zip(names[1:], results[1:]):
             line[nm] = r
-        if "text" in line and isinstance(line["text"], dict):
-            # `value` is BASELINE configs[1] (incompressible: DEFLATE's stored-block path).  The LZ77 + Huffman path the north star
-            # is about is configs[2]: its figures are lifted to the top level so that a parsed record carries both.
-            t = line["text"]
-            line["value_text"] = t["value"]
-            line["ms_per_step_text"] = t["ms_per_step"]
-            line["compress_GBps_text"], line["decompress_GBps_text"] = t["compress_GBps"], t["decompress_GBps"]
-            line["roofline_text_frac"] = t["roofline"]["frac"]
-            line["roofline_text_kernel"] = t["roofline"]["kernel"]
-            line["value_note"] = ("value = BASELINE configs[1] (10 000 x 256 KiB incompressible files: stored blocks); value_text = configs[2] (text-like, "
-                                  "dynamic-Huffman blocks) -- same size, same step, the LZ77 + Huffman kernels' figure")
-        print(json.dumps(line), flush=True)
+        if "random" in line and isinstance(line["random"], dict):
+            # `value` is BASELINE configs[2] (text-like: the LZ77 + Huffman kernels the north star is about).  configs[1] (incompressible:
+            # DEFLATE's stored-block path, a copy) is nested under "random", its headline figures lifted to the top level too.  (Rounds 1-4
+            # had it the other way round: value = configs[1], value_text = configs[2].)
+            t = line["random"]
+            line["value_random"] = t["value"]
+            line["ms_per_step_random"] = t["ms_per_step"]
+            line["compress_GBps_random"], line["decompress_GBps_random"] = t["compress_GBps"], t["decompress_GBps"]
+            line["roofline_random_frac"] = t["roofline"]["frac"]
+            line["roofline_random_kernel"] = t["roofline"]["kernel"]
+            # (the names rounds 1-4 used for the text figures, kept so that records compare across rounds)
+            line["value_text"], line["compress_GBps_text"], line["decompress_GBps_text"] = line["value"], line["compress_GBps"], line["decompress_GBps"]
+            line["roofline_text_frac"] = line["roofline"]["frac"]
+            line["value_note"] = ("value = BASELINE configs[2] (10 000 x 256 KiB text-like files: dynamic-Huffman blocks, the LZ77 + Huffman kernels); "
+                                  "value_random = configs[1] (incompressible files: stored blocks) -- same size, same step.  Until round 4 `value` was configs[1].")
     ok = all(r is None or r["verified"]["ok"] for r in results)
     codec.close()
+    e2e = None
+    if rank == 0 and world == 1 and args.workload == "both" and not args.no_e2e:
+        # What a user of the reference's command line sees (main.cpp:78-159): the product's `main compress` + `main decompress` on the same
+        # 10 000 x 256 KiB directories, on this box's file system, page cache warm.  NOT `value`: file I/O, PCIe and the process's fixed
+        # costs are in it.  The GPU workspace of the runs above is released first (two processes share the card for a moment).
+        del codec
+        torch.cuda.empty_cache()
+        e2e = e2e_legs(args)
+    if rank == 0:
+        if e2e is not None:
+            line["e2e"] = e2e
+            ok = ok and all(v.get("ok", True) for v in e2e.values() if isinstance(v, dict))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if not ok:

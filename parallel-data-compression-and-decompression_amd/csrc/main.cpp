@@ -390,14 +390,23 @@ int main(int argc, char* argv[]) {
         while (stat(output_path.c_str(), &st) != 0 && now_s() - t0 < rv.timeout_s) std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
 
+    const bool trace = getenv("ZWZ_VERBOSE") != nullptr || getenv("ZWZ_TIMELINE") != nullptr;
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); };
+    // Rank 0's file sort (file_sort.cpp:24-43) needs no GPU: it runs beside the context's creation (HIP start-up, the kernels' self-tests:
+    // 0.1 - 0.3 s; the sort of BASELINE configs[3]'s 370 000 files as long again).
+    char sorted_record[4096] = "";
+    int sort_rc = ZWZ_OK;
+    std::thread sort_thread;
+    const bool sort_here = operation == "compress" && world_rank == 0 && !getenv("ZWZ_FILE_RECORD");
+    if (sort_here) sort_thread = std::thread([&] { sort_rc = zwz_sort_files_by_size(source_path.c_str(), sorted_record, sizeof sorted_record);
+                                                    if (trace) fprintf(stderr, "zwz: file list sorted at %.3f s\n", since()); });
     int device_count = 0;
     zwz_device_count(&device_count);
     zwz_ctx* ctx = nullptr;
     const int dev = device_count > 0 ? env_int(dev_vars, world_rank) % device_count : 0;
     int rc = zwz_ctx_create(dev, 0, &ctx);
-    const bool trace = getenv("ZWZ_VERBOSE") != nullptr;
-    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); };
     if (trace) fprintf(stderr, "zwz: context ready at %.3f s\n", since());
+    if (sort_thread.joinable()) sort_thread.join();
     if (rc != ZWZ_OK) fprintf(stderr, "zwz: %s (%s)\n", zwz_strerror(rc), zwz_last_error());
 
     // ---- RCCL communicator (see struct Rccl): its id rides on the handshake's publication -- and only if EVERY rank can join:
@@ -425,7 +434,7 @@ int main(int argc, char* argv[]) {
         if (const char* fr = getenv("ZWZ_FILE_RECORD")) snprintf(record, sizeof record, "%s", fr);
         if (world_rank == 0) {
             printf("Compressing folder: %s\n", source_path.c_str());
-            if (rc == ZWZ_OK && !record[0]) rc = zwz_sort_files_by_size(source_path.c_str(), record, sizeof record);
+            if (sort_here) { snprintf(record, sizeof record, "%s", sorted_record); if (rc == ZWZ_OK) rc = sort_rc; }
             printf("File record saved location: %s\n", record);
             if (trace) fprintf(stderr, "zwz: file list ready at %.3f s\n", since());
             make_id();

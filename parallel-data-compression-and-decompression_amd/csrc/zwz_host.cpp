@@ -10,7 +10,10 @@
 #include <filesystem>
 #include <fstream>
 #include <map>
+#include <atomic>
+#include <iterator>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -59,11 +62,48 @@ int zwz_sort_files_by_size(const char* src_dir, char* record_path_out, size_t ca
         // the entry's own tail: the relative path is that tail, taken lexically.  Symlinks keep the reference's call.
         const std::string base_str = base.string();
         const size_t skip = base_str.size() + (base_str.empty() || base_str.back() == '/' ? 0 : 1);
-        for (const auto& e : fs::recursive_directory_iterator(base)) {
-            if (!e.is_regular_file()) continue;
+        auto take = [&](const fs::directory_entry& e, std::vector<Entry>& into) {
+            if (!e.is_regular_file()) return;
             const std::string& full = e.path().native();
             const bool plain = !e.is_symlink() && full.size() > skip && full.compare(0, base_str.size(), base_str) == 0;
-            files.push_back({plain ? full.substr(skip) : fs::relative(e.path(), base).string(), static_cast<off_t>(e.file_size())});
+            into.push_back({plain ? full.substr(skip) : fs::relative(e.path(), base).string(), static_cast<off_t>(e.file_size())});
+        };
+        // The walk is the reference's -- recursive_directory_iterator: a directory's entries in readdir order, a subdirectory's contents right
+        // behind its own entry -- but the subtrees under the top directory are walked by a few threads at once and spliced back in that order
+        // (370 000 files in 997 x 13 directories: 1.0 s of readdir + stat on one thread, a third of `main compress`).  The sequence handed
+        // to std::sort is the same, so ties come out the same.
+        struct Sub { size_t at; fs::path dir; std::vector<Entry> found; std::string error; };
+        std::vector<Sub> subs;
+        for (const auto& e : fs::directory_iterator(base)) {
+            if (e.is_directory() && !e.is_symlink()) subs.push_back({files.size(), e.path(), {}, {}});     // (the iterator does not descend into symlinked directories)
+            else take(e, files);
+        }
+        if (!subs.empty()) {
+            unsigned hc = std::thread::hardware_concurrency();
+            const unsigned nthreads = (unsigned)std::min<size_t>(subs.size(), hc <= 16u ? std::max(1u, hc) : std::min(32u, hc / 4u));
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= subs.size()) return;
+                    try { for (const auto& e : fs::recursive_directory_iterator(subs[i].dir)) take(e, subs[i].found); }
+                    catch (const std::exception& ex) { subs[i].error = ex.what(); }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nthreads; t++) { try { pool.emplace_back(work); } catch (const std::system_error&) { break; } }
+            work();
+            for (auto& t : pool) t.join();
+            std::vector<Entry> all;
+            size_t from = 0;
+            for (Sub& sb : subs) {
+                if (!sb.error.empty()) { set_error("%s", sb.error.c_str()); return ZWZ_E_IO; }
+                all.insert(all.end(), std::make_move_iterator(files.begin() + from), std::make_move_iterator(files.begin() + sb.at));
+                all.insert(all.end(), std::make_move_iterator(sb.found.begin()), std::make_move_iterator(sb.found.end()));
+                from = sb.at;
+            }
+            all.insert(all.end(), std::make_move_iterator(files.begin() + from), std::make_move_iterator(files.end()));
+            files.swap(all);
         }
         std::sort(files.begin(), files.end(), [](const Entry& a, const Entry& b) { return a.size > b.size; });
         fs::path out = base.parent_path() / "sorted_files_by_size.txt";   // file_sort.cpp:33

@@ -50,6 +50,9 @@ using namespace zwz;
 namespace {
 
 bool verbose() { static int v = getenv("ZWZ_VERBOSE") ? 1 : 0; return v != 0; }
+// ZWZ_TIMELINE=1: the phase timelines alone (stderr), without ZWZ_VERBOSE's per-file messages -- 10 000 "MD5 match" lines through a pipe
+// are a load of their own (tools/e2e.py measures with this)
+bool timeline() { static int v = (getenv("ZWZ_TIMELINE") || getenv("ZWZ_VERBOSE")) ? 1 : 0; return v != 0; }
 
 // Chunks per staging slice.  A slice costs 2 x 64 KiB of pinned host memory per chunk, twice (double buffering), and pinning is
 // slow (0.2 s for 4096-chunk slices, a quarter of a 2 GB job); 2048 chunks still give every CU eight chunks a launch.
@@ -125,6 +128,10 @@ private:
 
 unsigned host_threads() {
     if (const char* v = getenv("ZWZ_HOST_THREADS")) return (unsigned)std::max(1, atoi(v));
+    // Sixteen at most.  Measured on the GPU box (256 logical CPUs, overlay file system), BASELINE configs[1-3] through `main`: with 64 workers every
+    // stage that touches the file system got SLOWER -- the shard is one file (its writers queue on the inode lock), 10 000 output files land
+    // in one directory (their creates queue on the directory's), stat() of 370 000 files 0.25 -> 0.32 s -- slices of text 0.42 -> 0.51 s,
+    // decompress 0.77 -> 1.41 s.  The workers mostly wait for the kernel's locks, and more of them wait less efficiently.
     unsigned hc = std::thread::hardware_concurrency();
     return std::min(16u, std::max(2u, hc));
 }
@@ -137,6 +144,11 @@ struct Slices {
     uint64_t *h_off[2], *d_off[2];
     uint32_t *h_len[2], *h_olen[2], *h_st[2], *d_len[2], *d_olen[2], *d_st[2];
     hipEvent_t done[2] = {nullptr, nullptr};
+    // Three queues a slice passes through -- copy in (s_in), the codec's own stream, copy out (s_out) -- so that slice s + 1 arrives and
+    // slice s - 1 leaves while slice s is in the kernels (PCIe is full duplex; on ONE stream a text slice took 16.8 ms for ~5 ms of kernels).
+    // ev_in[b]: buffer pair b has arrived; ev_k[b]: its kernels are done (its d_in may be overwritten, its d_out copied out).
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
     // GPU MD5 of the files that lie whole inside a slice (zwz_md5_files_dev): (first slot, slots) per file in, 16 bytes out
     uint32_t *h_files[2] = {nullptr, nullptr}, *d_files[2] = {nullptr, nullptr};
     uint8_t *h_dig[2] = {nullptr, nullptr}, *d_dig[2] = {nullptr, nullptr};
@@ -160,7 +172,14 @@ int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
         carve(static_cast<uint8_t*>(c->h_stage), i, s.h_in[i], s.h_out[i], s.h_off[i], s.h_len[i], s.h_olen[i], s.h_st[i]);
         carve(static_cast<uint8_t*>(c->d_stage), i, s.d_in[i], s.d_out[i], s.d_off[i], s.d_len[i], s.d_olen[i], s.d_st[i]);
         hipError_t e = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_in[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_k[i], hipEventDisableTiming);
         if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&s.s_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.s_out, hipStreamNonBlocking);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
     }
     const size_t per = (size_t)cap * (8 + 16);                // a slice holds at most `cap` files
     hipError_t e = hipHostMalloc(&s.md5_host, 2 * per, hipHostMallocDefault);
@@ -175,7 +194,11 @@ int make_slices(zwz_ctx* c, uint32_t cap, Slices& s) {
 }
 
 void free_slices(Slices& s) {                 // (idempotent: scope guards call it again behind the timed call of the normal path)
+    if (s.s_in) { (void)hipStreamSynchronize(s.s_in); (void)hipStreamDestroy(s.s_in); s.s_in = nullptr; }
+    if (s.s_out) { (void)hipStreamSynchronize(s.s_out); (void)hipStreamDestroy(s.s_out); s.s_out = nullptr; }
     for (auto& e : s.done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : s.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : s.ev_k) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (s.md5_host) { (void)hipHostFree(s.md5_host); s.md5_host = nullptr; }
     if (s.md5_dev) { (void)hipFree(s.md5_dev); s.md5_dev = nullptr; }
 }
@@ -246,7 +269,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     const uint32_t chunk_bytes = chunk_bytes_for(c);
     const auto t_entry = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {          // ZWZ_VERBOSE: the pipeline's own timeline
-        if (verbose()) fprintf(stderr, "zwz: [%.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(), what);
+        if (timeline()) fprintf(stderr, "zwz: [%.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(), what);
     };
     std::vector<std::string> lines;
     {
@@ -266,6 +289,15 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     uint64_t total_chunks = 0;
     mark("file list read");
     Pool pool(host_threads());
+    // The pinned staging (0.1 s for 2 x 2 048 chunks: hipHostMalloc pins page by page) is allocated by a helper thread while this one sizes the
+    // files; its size only needs an upper bound of the chunk count, which the list's length gives for the common case (cap is re-derived below).
+    HIPCHK(hipSetDevice(c->device));
+    std::thread staging_thread;
+    int staging_rc = ZWZ_OK;
+    const uint32_t early_cap = std::max(1u, std::min(c->max_batch, kSliceChunks));
+    const bool early_staging = lines.size() / (size_t)nranks >= early_cap;        // at least a slice's worth of files: the full-size staging is what will be asked for
+    if (early_staging) staging_thread = std::thread([&] { (void)hipSetDevice(c->device); staging_rc = ensure_staging(c, 2 * early_cap); });
+    struct JoinStaging { std::thread& t; ~JoinStaging() { if (t.joinable()) t.join(); } } join_staging{staging_thread};
     {   // Sizes come from stat(), on the pool; a file is opened only by the task that reads it and closed right after.
         // (Holding every source file open needed one descriptor per file -- 370 k of them in BASELINE's config 4 -- and
         // grew the descriptor table step by step, each step a synchronize_rcu() in a process the HIP runtime has made
@@ -279,9 +311,10 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
             cand.push_back(std::move(f));
         }
         Pool::Group stat_group;
-        for (size_t i0 = 0; i0 < cand.size(); i0 += 256)
-            pool.submit(stat_group, [&cand, i0] {
-                for (size_t i = i0; i < std::min(cand.size(), i0 + 256); i++) {
+        const size_t stat_per = std::max<size_t>(32, std::min<size_t>(256, cand.size() / (4 * host_threads()) + 1));
+        for (size_t i0 = 0; i0 < cand.size(); i0 += stat_per)
+            pool.submit(stat_group, [&cand, i0, stat_per] {
+                for (size_t i = i0; i < std::min(cand.size(), i0 + stat_per); i++) {
                     File& f = cand[i];
                     struct stat sb;
                     if (stat(f.full.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && access(f.full.c_str(), R_OK) == 0) { f.ok = true; f.size = (uint64_t)sb.st_size; }
@@ -305,13 +338,14 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     const int dest = open(out_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (dest < 0) { set_error("cannot create %s", out_path.c_str()); return ZWZ_E_IO; }
 
-    HIPCHK(hipSetDevice(c->device));
     const uint32_t T = (uint32_t)total_chunks;
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, (T + 1) / 2 + 1)));
     Slices sl;
     const double t_alloc0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (staging_thread.joinable()) staging_thread.join();
+    if (staging_rc) { close(dest); return staging_rc; }
     int rc = make_slices(c, cap, sl);
-    if (verbose()) fprintf(stderr, "zwz: staging for 2 x %u chunks allocated in %.3f s\n", cap,
+    if (timeline()) fprintf(stderr, "zwz: staging for 2 x %u chunks ready after another %.3f s (pinned beside the file sizing)\n", cap,
                            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_alloc0);
     if (rc) { free_slices(sl); close(dest); return rc; }
     const uint32_t nslices = (T + cap - 1) / cap;
@@ -365,6 +399,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
         // 64 chunks or 32 files, whichever comes first (370 000 one-chunk files as 370 000 tasks spent more time in the
         // pool's queue than in pread()).
         struct Unit { uint32_t fi, u0, u1; bool hash_here; };
+        const uint32_t task_chunks = std::max(16u, std::min(64u, cap / (2u * host_threads())));   // every worker gets a couple of tasks a slice
         std::vector<Unit> batch;
         uint32_t batch_chunks = 0;
         auto flush = [&] {
@@ -417,7 +452,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
                 }
                 batch.push_back({fi, u0, u1, one_unit && !gpu_md5});
                 batch_chunks += u1 - u0;
-                if (batch_chunks >= 64 || batch.size() >= 32) flush();
+                if (batch_chunks >= task_chunks || batch.size() >= 32) flush();
             }
             g += c1 - c0;
         }
@@ -435,21 +470,30 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     auto launch_gpu = [&](uint32_t s) -> int {
         const int b = (int)(s & 1u);
         const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
-        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        // copy in (its own queue): the pair's device buffers were last read by the kernels of slice s - 2
+        if (s >= 2) HIPCHK(hipStreamWaitEvent(sl.s_in, sl.ev_k[b], 0));
+        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, sl.s_in));
+        if (sl.n_md5[b]) HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipEventRecord(sl.ev_in[b], sl.s_in));
+        // the kernels (the codec's stream): behind the copy in, and behind the copy out of slice s - 2, which read d_out[b]
+        HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_in[b], 0));
+        if (s >= 2) HIPCHK(hipStreamWaitEvent(c->stream, sl.done[b], 0));
         // offsets are relative to this slice's d_in
         int r = zwz_deflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b]);
         if (r) return r;
         if (sl.n_md5[b]) {
-            HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, c->stream));
             r = zwz_md5_files_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], sl.d_files[b], sl.n_md5[b], sl.d_dig[b]);
             if (r) return r;
-            HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(sl.done[b], c->stream));
+        HIPCHK(hipEventRecord(sl.ev_k[b], c->stream));
+        // copy out (its own queue)
+        HIPCHK(hipStreamWaitEvent(sl.s_out, sl.ev_k[b], 0));
+        if (sl.n_md5[b]) HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipEventRecord(sl.done[b], sl.s_out));
         return ZWZ_OK;
     };
     // data_writer(), compression.cpp:73-104.  The shard is one file, but every record's place in it is known once the
@@ -506,42 +550,43 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
             }
             recs.push_back(r);
         }
-        const size_t n = recs.size(), per = std::max<size_t>(64, (n + 2 * host_threads() - 1) / (2 * host_threads()));
-        for (size_t r0 = 0; r0 < n; r0 += per) {
-            const size_t r1 = std::min(n, r0 + per);
-            pool.submit(write_group, [&, b, r0, r1] {
-                std::vector<int32_t> hdr;  hdr.reserve(4 * (r1 - r0));       // total, path_len | seq per record
-                std::vector<struct iovec> iov; iov.reserve(6 * (r1 - r0));
-                for (size_t i = r0; i < r1; i++) {
-                    const Rec& r = recs[i];
-                    hdr.push_back(4 + r.path_len + 4 + 1 + r.payload); hdr.push_back(r.path_len); hdr.push_back(r.seq); hdr.push_back(0);
+        // ONE writer, this thread.  The shard is one file and the kernel serialises buffered writes to an inode: sixteen workers with
+        // pwritev on their own runs of records (rounds 1-4) wrote it at 4 - 8 GB/s, each waiting for the others' lock; one thread writing
+        // the records in order reaches 8.5 (tmpfs) to 13 GB/s (the box's overlay file system) -- tools/exp/shard_write.cpp.  The GPU works on
+        // the next slice and the pool reads the one after it meanwhile.
+        {
+            const size_t n = recs.size();
+            std::vector<int32_t> hdr;  hdr.reserve(4 * n);                   // total, path_len | seq per record
+            std::vector<struct iovec> iov; iov.reserve(6 * n);
+            for (size_t i = 0; i < n; i++) {
+                const Rec& r = recs[i];
+                hdr.push_back(4 + r.path_len + 4 + 1 + r.payload); hdr.push_back(r.path_len); hdr.push_back(r.seq); hdr.push_back(0);
+            }
+            for (size_t i = 0; i < n; i++) {
+                const Rec& r = recs[i];
+                int32_t* h = hdr.data() + 4 * i;
+                iov.push_back({h, 8});
+                iov.push_back({const_cast<char*>(r.rel->data()), (size_t)r.path_len});
+                iov.push_back({h + 2, 4});
+                iov.push_back({const_cast<uint8_t*>(&r.last), 1});
+                iov.push_back({sl.h_out[b] + (size_t)r.slot * ZWZ_DEV_STRIDE, (size_t)r.payload});
+                if (r.last) iov.push_back({const_cast<char*>(r.md5), 32});
+            }
+            uint64_t off = n ? recs[0].off : 0;
+            size_t k = 0;
+            while (k < iov.size()) {                                         // pwritev: at most IOV_MAX pieces a call, and it may stop short
+                if (iov[k].iov_len == 0) { k++; continue; }
+                const int cnt = (int)std::min<size_t>(1024, iov.size() - k);
+                ssize_t w = pwritev(dest, iov.data() + k, cnt, (off_t)off);
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) { write_error.store(1); break; }
+                off += (uint64_t)w;
+                size_t left = (size_t)w;
+                while (left) {
+                    if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
+                    else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
                 }
-                for (size_t i = r0; i < r1; i++) {
-                    const Rec& r = recs[i];
-                    int32_t* h = hdr.data() + 4 * (i - r0);
-                    iov.push_back({h, 8});
-                    iov.push_back({const_cast<char*>(r.rel->data()), (size_t)r.path_len});
-                    iov.push_back({h + 2, 4});
-                    iov.push_back({const_cast<uint8_t*>(&r.last), 1});
-                    iov.push_back({sl.h_out[b] + (size_t)r.slot * ZWZ_DEV_STRIDE, (size_t)r.payload});
-                    if (r.last) iov.push_back({const_cast<char*>(r.md5), 32});
-                }
-                uint64_t off = recs[r0].off;
-                size_t k = 0;
-                while (k < iov.size()) {                                     // pwritev: at most IOV_MAX pieces a call, and it may stop short
-                    if (iov[k].iov_len == 0) { k++; continue; }
-                    const int cnt = (int)std::min<size_t>(512, iov.size() - k);
-                    ssize_t w = pwritev(dest, iov.data() + k, cnt, (off_t)off);
-                    if (w < 0 && errno == EINTR) continue;
-                    if (w <= 0) { write_error.store(1); return; }
-                    off += (uint64_t)w;
-                    size_t left = (size_t)w;
-                    while (left) {
-                        if (left >= iov[k].iov_len) { left -= iov[k].iov_len; k++; }
-                        else { iov[k].iov_base = static_cast<char*>(iov[k].iov_base) + left; iov[k].iov_len -= left; left = 0; }
-                    }
-                }
-            });
+            }
         }
         pool.wait(write_group);                 // the slice's buffers go back to the GPU next
     };
@@ -579,7 +624,7 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
         if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize"); else { count_truncated(nslices - 1); write_records(nslices - 1); }
         t_write += now() - t0;
     }
-    if (verbose())
+    if (timeline())
         fprintf(stderr, "zwz: %u slices of <= %u chunks in %.3f s: waiting for reads %.3f s, for the GPU %.3f s, writing %.3f s\n",
                 nslices, cap, now() - t_begin, t_read, t_gpu, t_write);
     mark("last slice written");
@@ -588,14 +633,14 @@ int compress_dir_impl(zwz_ctx* c, const char* src_dir, const char* dst_dir, cons
     mark("workers and stream idle");
     const double t_free0 = now();
     free_slices(sl);
-    if (verbose()) fprintf(stderr, "zwz: staging released in %.3f s\n", now() - t_free0);
+    if (timeline()) fprintf(stderr, "zwz: staging released in %.3f s\n", now() - t_free0);
     if (write_error.load() && rc == ZWZ_OK) { set_error("writing %s failed", out_path.c_str()); rc = ZWZ_E_IO; }
     dest_open = -1;
     if (close(dest) != 0 && rc == ZWZ_OK) rc = ZWZ_E_IO;
     mark("shard closed");
     if (io_error.load() && rc == ZWZ_OK) { set_error("a source file changed or vanished while it was being read"); rc = ZWZ_E_IO; }
     { std::string why; if (pool.failed(&why) && rc == ZWZ_OK) { set_error("a pipeline task failed: %s", why.c_str()); rc = ZWZ_E_IO; } }
-    if (truncated && verbose())
+    if (truncated && timeline())
         fprintf(stderr, "zwz: %u chunk payload(s) reached the reference's 65535-byte cap (lossy, like the reference)\n", truncated);
     return rc;
 }
@@ -819,8 +864,9 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
                 }
                 g = e;
             }
-        for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
-            const uint32_t u1 = std::min(g1, u0 + 256);
+        const uint32_t per_task = std::max(32u, std::min(256u, cap / (2u * host_threads())));
+        for (uint32_t u0 = g0; u0 < g1; u0 += per_task) {
+            const uint32_t u1 = std::min(g1, u0 + per_task);
             pool.submit(fill_group[b], [&, b, g0, u0, u1] {
                 for (uint32_t g = u0; g < u1; g++) {
                     const Rec& r = jobs[g].r;
@@ -835,20 +881,27 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     auto launch_gpu = [&](uint32_t s) -> int {
         const int b = (int)(s & 1u);
         const uint32_t m = std::min(T, (s + 1) * cap) - s * cap;
-        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        // three queues, as on the compress side (see Slices)
+        if (s >= 2) HIPCHK(hipStreamWaitEvent(sl.s_in, sl.ev_k[b], 0));
+        HIPCHK(hipMemcpyAsync(sl.d_in[b], sl.h_in[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipMemcpyAsync(sl.d_len[b], sl.h_len[b], m * sizeof(uint32_t), hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipMemcpyAsync(sl.d_off[b], sl.h_off[b], m * sizeof(uint64_t), hipMemcpyHostToDevice, sl.s_in));
+        if (sl.n_md5[b]) HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, sl.s_in));
+        HIPCHK(hipEventRecord(sl.ev_in[b], sl.s_in));
+        HIPCHK(hipStreamWaitEvent(c->stream, sl.ev_in[b], 0));
+        if (s >= 2) HIPCHK(hipStreamWaitEvent(c->stream, sl.done[b], 0));
         int r = zwz_inflate_batch_dev(c, sl.d_in[b], sl.d_off[b], sl.d_len[b], m, sl.d_out[b], ZWZ_DEV_STRIDE, sl.d_olen[b], sl.d_st[b]);
         if (r) return r;
         if (sl.n_md5[b]) {      // (output slot k sits at k * 65536, which is what d_off holds for the input slots)
-            HIPCHK(hipMemcpyAsync(sl.d_files[b], sl.h_files[b], (size_t)sl.n_md5[b] * 8, hipMemcpyHostToDevice, c->stream));
             r = zwz_md5_files_dev(c, sl.d_out[b], sl.d_off[b], sl.d_olen[b], sl.d_files[b], sl.n_md5[b], sl.d_dig[b]);
             if (r) return r;
-            HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(sl.done[b], c->stream));
+        HIPCHK(hipEventRecord(sl.ev_k[b], c->stream));
+        HIPCHK(hipStreamWaitEvent(sl.s_out, sl.ev_k[b], 0));
+        if (sl.n_md5[b]) HIPCHK(hipMemcpyAsync(sl.h_dig[b], sl.d_dig[b], (size_t)sl.n_md5[b] * 16, hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)m * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], m * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.s_out));
+        HIPCHK(hipEventRecord(sl.done[b], sl.s_out));
         return ZWZ_OK;
     };
     // One task per file that has records in this slice -- a file decoded within one slice is written (stdio) and hashed
@@ -939,7 +992,7 @@ int decode_whole_shard(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     }
     const double t_slices = since();
     pool.wait(fill_group[0]); pool.wait(fill_group[1]); pool.wait(md5_group);
-    if (verbose()) fprintf(stderr, "zwz: decode: %u records of %zu files in %u slices done at %.3f s (waited %.3f s for the GPU, %.3f s for the writers); "
+    if (timeline()) fprintf(stderr, "zwz: decode: %u records of %zu files in %u slices done at %.3f s (waited %.3f s for the GPU, %.3f s for the writers); "
                                    "spanning files hashed by %.3f s\n", T, insts.size(), nslices, t_slices, t_gpu_wait, t_write_wait, since());
     (void)hipStreamSynchronize(c->stream);
     free_slices(sl);
@@ -1009,8 +1062,9 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     auto start_fill = [&](uint32_t s) {
         const int b = (int)(s & 1u);
         const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
-        for (uint32_t u0 = g0; u0 < g1; u0 += 256) {
-            const uint32_t u1 = std::min(g1, u0 + 256);
+        const uint32_t per_task = std::max(32u, std::min(256u, cap / (2u * host_threads())));
+        for (uint32_t u0 = g0; u0 < g1; u0 += per_task) {
+            const uint32_t u1 = std::min(g1, u0 + per_task);
             pool.submit(fill_group[b], [&, b, g0, u0, u1] {
                 for (uint32_t g = u0; g < u1; g++) {
                     const Rec& r = jobs[j0 + g].r;
@@ -1053,7 +1107,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
                     if (hipMalloc(reinterpret_cast<void**>(&d_big), (size_t)chunks * ZWZ_DEV_STRIDE) == hipSuccess) { res = chunks; break; }
                     (void)hipGetLastError(); d_big = nullptr; want /= 2;
                 }
-                if (verbose()) fprintf(stderr, "zwz: split decode: rank %d holds %u of its %u chunks on the device between the phases (%u slices of %u)\n", rank, res, n, nslices, cap);
+                if (timeline()) fprintf(stderr, "zwz: split decode: rank %d holds %u of its %u chunks on the device between the phases (%u slices of %u)\n", rank, res, n, nslices, cap);
             }
         }
         // ---- phase 1: payloads in, range inflated; the first `res` chunks stay, of the others only the decoded lengths come back

@@ -41,6 +41,8 @@ def test_cpu_baseline_tree_times_the_reference_on_a_small_tree(bench):
     if os.path.exists(bench.REF_MAIN):
         assert r["value"] > 0 and r["compress_GBps"] > 0 and r["decompress_GBps"] > 0 and r["ranks"]["1"]["bytes"] == 202070
         assert r["ranks"]["1"]["compress_banner_s"] is not None          # the reference's own "Time Taken" was found on its stdout
+        if "2" in r["ranks"] and "error" not in r["ranks"]["2"]:
+            assert r["ranks"]["2"]["compress_banner_s"] is not None      # ... and with two ranks sharing a stdout: from rank 0's own file
     else:
         assert r["value"] is None and "absent" in r["note"]
 

@@ -542,5 +542,6 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["comm"]["ranks_seen"] == 2 and d["comm"]["backend"] == "gloo"
     assert len(d["ms_per_step_by_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_by_rank"])
     assert d["verified"]["ok"] and d["verified"]["ranks_failed"] == 0
-    assert d["text"]["verified"]["ok"] and len(d["text"]["ms_per_step_by_rank"]) == 2
-    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["random"]["verified"]["ok"] and len(d["random"]["ms_per_step_by_rank"]) == 2        # (the line's own fields are the text configuration's)
+    assert d["value"] > 0 and d["value"] == d["value_text"] and d["value_random"] == d["random"]["value"] and d["scaling"] == "weak"
+    assert "e2e" not in d                                                                            # the CLI legs are a one-rank affair

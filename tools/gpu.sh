@@ -35,10 +35,13 @@ bench_table() {    # <json file>: the line's headline figures
 python3 - "$1" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-rows = [(d["config"]["workload"][:40], d)] + ([("text", d["text"])] if isinstance(d.get("text"), dict) else [])
+rows = [(d["config"]["workload"][:40], d)] + [(k, d[k]) for k in ("text", "random") if isinstance(d.get(k), dict)]
 for nm, r in rows:
     print(nm, "value", r.get("value"), "c", r.get("compress_GBps"), "d", r.get("decompress_GBps"), "ok", r.get("verified", {}).get("ok"), r.get("stage_ms_per_pass"))
     if r.get("cpu_baseline"): print("   cpu", r["cpu_baseline"].get("value"), r["cpu_baseline"].get("compress_GBps"), r["cpu_baseline"].get("decompress_GBps"), r["cpu_baseline"].get("note"))
+for k, v in (d.get("e2e") or {}).items():
+    if isinstance(v, dict): print("e2e", k, v.get("filesystem"), "compress", v["compress"].get("banner_s"), "s", v["compress"].get("GBps"), "GB/s steady", v["compress"].get("steady_GBps"), "| decompress", v["decompress"].get("banner_s"), "s", v["decompress"].get("GBps"), "GB/s steady", v["decompress"].get("steady_GBps"), "ok", v.get("ok"))
+    else: print("e2e", k, v)
 PY
 }
 
