@@ -151,10 +151,13 @@ int zwz_ctx_set_chunk_size(zwz_ctx *ctx, uint32_t bytes);
  * compression.cpp:119-134 / decompression.cpp:16-36) and no effect on any byte produced -- they choose between kernels that compute
  * the same thing, so that tests can drive each of them and a device that fails a self-test at zwz_ctx_create still gets a codec:
  *   "match"           "auto" (default: per chunk, by a sample of its trigrams) | "walk" (chain links + walk) | "band" (sort + banded search)
+ *                     | "lazy" (sort + lz_lazy: search and lazy parse in one kernel, the searches on demand) | "autoband" / "autolazy"
+ *                     (the per-chunk choice with the band / lz_lazy for chain-heavy chunks; "auto" is "autoband")
  *   "plan"            "wave" (default) | "serial"   block flush: a lane per heap + a wave per block, or all of it on one lane
  *   "inflate_header"  "wave" (default) | "serial"   a block's decoding tables by the whole wave, or by lane 0
- * Defaults come from ZWZ_MATCH / ZWZ_PLAN / ZWZ_INFLATE_HEADER, read once in zwz_ctx_create (never per launch).  ZWZ_E_INVALID for
- * an unknown name or value. */
+ * Defaults come from ZWZ_MATCH / ZWZ_PLAN / ZWZ_INFLATE_HEADER, read once in zwz_ctx_create (never per launch; a value that is not
+ * understood is reported on stderr and ignored).  ZWZ_E_INVALID for an unknown name or value; ZWZ_E_NO_DEVICE for a kernel form
+ * that failed its self-test on this device at zwz_ctx_create -- it stays off ("auto" / "" then mean what the device can run). */
 int zwz_ctx_set_option(zwz_ctx *ctx, const char *name, const char *value);
 
 #ifdef __cplusplus

@@ -221,8 +221,9 @@ class Codec:
         return bad.value
 
     def set_option(self, name, value):
-        """Test / experiment switches of this context (include/zwz.h: zwz_ctx_set_option): "match" = auto | walk | band,
-        "plan" = wave | serial, "inflate_header" = wave | serial.  Every choice produces the same bytes."""
+        """Test / experiment switches of this context (include/zwz.h: zwz_ctx_set_option): "match" = auto | walk | band | lazy |
+        autoband | autolazy, "plan" = wave | serial, "inflate_header" = wave | serial.  Every choice produces the same bytes; a form that
+        failed its self-test on this device is refused."""
         _check(lib().zwz_ctx_set_option(self._h, name.encode(), value.encode()), "zwz_ctx_set_option")
 
     def set_chunk_size(self, nbytes):

@@ -3,6 +3,7 @@
 #include "zwz_api_internal.h"
 
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
@@ -178,13 +179,13 @@ int codec_self_test(zwz_ctx* c) {
         if (rc != ZWZ_OK) return rc;
         bool same = true;
         for (uint32_t k = 0; k < K; k++) same = same && l_wave[k] == l_serial[k] && !memcmp(p_wave.data() + (size_t)k * ZWZ_CHUNK_SIZE, p_serial.data() + (size_t)k * ZWZ_CHUNK_SIZE, l_serial[k]);
-        if (!same) { c->plan_serial = 1; fprintf(stderr, "zwz: the wave form of the block flush disagrees with the lane-serial one on this device: using the lane-serial kernel\n"); }
+        if (!same) { c->plan_serial = 1; c->forbidden |= kForbidPlanWave; fprintf(stderr, "zwz: the wave form of the block flush disagrees with the lane-serial one on this device: using the lane-serial kernel\n"); }
     }
     if (!keep_hdr) {
         c->inflate_serial_header = 0;
         rc = zwz_inflate_batch(c, p_serial.data(), poffs, l_serial, K, back.data(), l_back, st);
         if (rc != ZWZ_OK) return rc;
-        if (!same_as_input()) { c->inflate_serial_header = 1; fprintf(stderr, "zwz: inflate's wave-built tables decode wrongly on this device: block headers go to lane 0\n"); }
+        if (!same_as_input()) { c->inflate_serial_header = 1; c->forbidden |= kForbidInflateWave; fprintf(stderr, "zwz: inflate's wave-built tables decode wrongly on this device: block headers go to lane 0\n"); }
     }
     return ZWZ_OK;
 }
@@ -238,9 +239,14 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
         fprintf(stderr, "zwz: EXPERIMENT BUILD (ZWZ_MATCH_EXP=%u ZWZ_PARSE_EXP=%u ZWZ_ENC_EXP=%u ZWZ_INF_EXP=%u ZWZ_BAND_EXP=%u): timings only, not the product library\n",
                 xk & 255u, (xk >> 8) & 255u, (xk >> 16) & 255u, xk >> 24, xb);
     // Test switches, read ONCE per context (a stray variable is still honoured, but no launch re-reads the environment: ADVICE r3)
-    if (const char* v = getenv("ZWZ_MATCH")) (void)zwz_ctx_set_option(c, "match", v);
-    if (const char* v = getenv("ZWZ_PLAN")) (void)zwz_ctx_set_option(c, "plan", v);
-    if (const char* v = getenv("ZWZ_INFLATE_HEADER")) (void)zwz_ctx_set_option(c, "inflate_header", v);
+    // (a value that is not understood is said so: ZWZ_MATCH=bnad used to be ignored without a word)
+    auto from_env = [&](const char* var, const char* option) {
+        if (const char* v = getenv(var)) if (zwz_ctx_set_option(c, option, v) != ZWZ_OK) fprintf(stderr, "zwz: %s=%s is not a value of option \"%s\": ignored\n", var, v, option);
+    };
+    from_env("ZWZ_MATCH", "match"); from_env("ZWZ_PLAN", "plan"); from_env("ZWZ_INFLATE_HEADER", "inflate_header");
+    const bool tl = getenv("ZWZ_TIMELINE") != nullptr || getenv("ZWZ_VERBOSE") != nullptr;
+    const auto t_create = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) { if (tl) fprintf(stderr, "zwz: context: %s at +%.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count()); };
     // Three kernels stand on LDS behaviour the ISA manual does not promise: lz_links on the lane order of
     // ds_wrxchg_rtn, lz_sort / the wave plan / inflate's wave-built tables on that of ds_add_rtn.  Each is checked here against a
     // host restatement or its own order-free form; a failed check selects the form that does not need the property, and only a
@@ -249,8 +255,10 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
         bool xchg_ok = false;
         e = probe_exchange_order(c->stream, &xchg_ok);
         if (e != hipSuccess) { int rc = hip_fail(e, "zwz_ctx_create: exchange-order probe"); zwz_ctx_destroy(c); return rc; }
+        mark("exchange-order probe done");
         uint32_t bad = 0;
         const int rc = links_self_test(c, &bad);
+        mark("lz_links / lz_sort known-answer tests done");
         if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; }
         const bool links_ok = xchg_ok && !(bad & 1u), sort_ok = !(bad & 2u);
         if (!links_ok && !sort_ok) {
@@ -258,6 +266,14 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
             zwz_ctx_destroy(c);
             return ZWZ_E_NO_DEVICE;
         }
+        // (a test hook: ZWZ_FORCE_SELFTEST_FAIL=links|sort pretends that check failed, so that the fallback configurations run through the
+        //  oracle comparison once -- tests/test_gpu_codec.py)
+        const char* force = getenv("ZWZ_FORCE_SELFTEST_FAIL");
+        const bool f_links = force && strstr(force, "links"), f_sort = force && strstr(force, "sort");
+        if (!links_ok || f_links) c->forbidden |= kForbidLinks;
+        if (!sort_ok || f_sort) c->forbidden |= kForbidSort | kForbidPlanWave | kForbidInflateWave;
+        if (f_links && !f_sort) { c->match_mode = kMatchBand; fprintf(stderr, "zwz: (forced) lz_links counts as failed: every chunk takes the sort + band search\n"); }
+        if (f_sort) { c->match_mode = kMatchWalk; c->plan_serial = 1; c->inflate_serial_header = 1; fprintf(stderr, "zwz: (forced) lz_sort counts as failed: chain walk, lane-serial block flush and inflate headers\n"); }
         if (!links_ok) { c->match_mode = kMatchBand; fprintf(stderr, "zwz: lz_links' exchange order does not hold on this device: every chunk takes the sort + band search (%s)\n", zwz_last_error()); }
         if (!sort_ok) {
             c->match_mode = kMatchWalk; c->plan_serial = 1; c->inflate_serial_header = 1;
@@ -265,6 +281,7 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
         }
     }
     { const int rc = codec_self_test(c); if (rc != ZWZ_OK) { zwz_ctx_destroy(c); return rc; } }
+    mark("codec known-answer test done");
     *out = c;
     return ZWZ_OK;
 }
@@ -272,13 +289,25 @@ int zwz_ctx_create(int device, uint32_t max_batch, zwz_ctx** out) {
 int zwz_ctx_set_option(zwz_ctx* c, const char* name, const char* value) {
     if (!c || !name || !value) return ZWZ_E_INVALID;
     const std::string n = name, v = value;
+    // A form this device failed its self-test of stays off (include/zwz.h promises the same bytes from every setting, which a
+    // failing kernel form would break): asking for it is ZWZ_E_NO_DEVICE, and "auto" / "wave" keep meaning "what this device can run".
+    const bool no_links = c->forbidden & kForbidLinks, no_sort = c->forbidden & kForbidSort;
+    auto refuse = [&](const char* what) { set_error("zwz_ctx_set_option: %s=%s needs a kernel form that failed its self-test on this device", what, v.c_str()); return ZWZ_E_NO_DEVICE; };
     if (n == "match") {
-        if (v == "auto" || v.empty()) c->match_mode = kMatchAuto; else if (v == "walk") c->match_mode = kMatchWalk; else if (v == "band") c->match_mode = kMatchBand; else if (v == "lazy") c->match_mode = kMatchLazy;
-        else if (v == "autoband") c->match_mode = kMatchAutoBand; else if (v == "autolazy") c->match_mode = kMatchAutoLazy; else return ZWZ_E_INVALID;
+        uint32_t m;
+        if (v == "auto" || v.empty()) m = kMatchAuto; else if (v == "walk") m = kMatchWalk; else if (v == "band") m = kMatchBand; else if (v == "lazy") m = kMatchLazy;
+        else if (v == "autoband") m = kMatchAutoBand; else if (v == "autolazy") m = kMatchAutoLazy; else return ZWZ_E_INVALID;
+        const bool needs_links = m == kMatchAuto || m == kMatchWalk || m == kMatchAutoBand || m == kMatchAutoLazy;
+        const bool needs_sort = m == kMatchAuto || m == kMatchBand || m == kMatchLazy || m == kMatchAutoBand || m == kMatchAutoLazy;
+        if (m == kMatchAuto && (no_links || no_sort)) m = no_sort ? kMatchWalk : kMatchBand;          // "auto" on a device with one search left: that one
+        else if ((needs_links && no_links) || (needs_sort && no_sort)) return refuse("match");
+        c->match_mode = m;
     } else if (n == "plan") {
-        if (v == "wave" || v.empty()) c->plan_serial = 0; else if (v == "serial") c->plan_serial = 1; else return ZWZ_E_INVALID;
+        if (v == "wave" || v.empty()) { if (c->forbidden & kForbidPlanWave) { if (v.empty()) return ZWZ_OK; return refuse("plan"); } c->plan_serial = 0; }
+        else if (v == "serial") c->plan_serial = 1; else return ZWZ_E_INVALID;
     } else if (n == "inflate_header") {
-        if (v == "wave" || v.empty()) c->inflate_serial_header = 0; else if (v == "serial") c->inflate_serial_header = 1; else return ZWZ_E_INVALID;
+        if (v == "wave" || v.empty()) { if (c->forbidden & kForbidInflateWave) { if (v.empty()) return ZWZ_OK; return refuse("inflate_header"); } c->inflate_serial_header = 0; }
+        else if (v == "serial") c->inflate_serial_header = 1; else return ZWZ_E_INVALID;
     } else return ZWZ_E_INVALID;
     return ZWZ_OK;
 }

@@ -24,6 +24,8 @@ struct zwz_ctx {
     uint32_t match_mode = 0;             // zwz::kMatchAuto | kMatchWalk | kMatchBand
     uint32_t plan_serial = 0;            // 1: lane-serial block flush
     uint32_t inflate_serial_header = 0;  // 1: block headers and tables on lane 0
+    // Kernel forms this device failed a self-test of at zwz_ctx_create (kForbid*): zwz_ctx_set_option refuses to switch them back on
+    uint32_t forbidden = 0;
     bool profiling = false;
     hipEvent_t ev[zwz::kNumDeflateStages + 1] = {};
     hipEvent_t ev_inf[2] = {};
@@ -31,6 +33,8 @@ struct zwz_ctx {
 };
 
 namespace zwz {
+
+enum : uint32_t { kForbidLinks = 1u, kForbidSort = 2u, kForbidPlanWave = 4u, kForbidInflateWave = 8u };   // zwz_ctx::forbidden
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

@@ -306,6 +306,30 @@ def test_inflate_matches_oracle(codec, oracle):
         assert g == w, (len(p), len(g), len(w), s, st)
 
 
+@pytest.mark.parametrize("failed", ["links", "sort"])
+def test_a_failed_self_test_keeps_its_kernel_forms_off(zwz, oracle, failed, monkeypatch):
+    """a context whose self-test of lz_links (or of lz_sort's ordered adds) failed falls back to the forms that do not need the
+    property -- and zwz_ctx_set_option must not switch the failing forms back on (include/zwz.h promises the same bytes from every
+    setting).  ZWZ_FORCE_SELFTEST_FAIL pretends the failure: the fallback configuration runs through the oracle comparison, asking for
+    a forbidden form is an error, "auto" keeps meaning what the device can run, and a mistyped ZWZ_MATCH is reported, not swallowed."""
+    monkeypatch.setenv("ZWZ_FORCE_SELFTEST_FAIL", failed)
+    codec = zwz.Codec(0, 256)
+    forbidden = [("match", "walk"), ("match", "autoband")] if failed == "links" else [("match", "band"), ("match", "lazy"), ("plan", "wave"), ("inflate_header", "wave")]
+    for name, value in forbidden:
+        with pytest.raises(zwz.ZwzError):
+            codec.set_option(name, value)
+    codec.set_option("match", "auto")                     # = the search this device has left
+    codec.set_option("plan", "serial")
+    chunks = [corpus.make(kind, 8800 + i, n) for kind in corpus.KINDS for i, n in enumerate([0, 3, 300, 20000, 65535]) if not (kind == "lz" and n > 20000)]
+    got = codec.deflate_chunks(chunks)
+    for c, g in zip(chunks, got):
+        assert g == oracle.payload(c), (failed, len(c))
+    back, status = codec.inflate_chunks(got)
+    for g, b in zip(got, back):
+        assert b == oracle.inflate(g, 65535)[0]
+    codec.close()
+
+
 def test_inflate_serial_header_option_matches_oracle(zwz, oracle):
     """The order-free form of the block header (option inflate_header=serial: tables by lane 0, inflate_core.h's inflate_block_rest) --
     what a context falls back to when its known-answer test of the wave-built tables fails -- decodes like the oracle: whole
