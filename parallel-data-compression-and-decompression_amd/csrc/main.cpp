@@ -277,51 +277,59 @@ struct Rccl {
     // file ("" or unreadable: the rank contributes nothing, e.g. because it failed or had no file to compress).
     static constexpr size_t kPiece = (size_t)64 << 20;
     bool gather_files(const std::string& my_path, const std::string& out_dir) {
+        // Two kinds of failure, kept apart.  comm_ok: an RCCL or HIP call failed -- nothing further can be matched, the loops end.
+        // io_failed: a shard could not be read or stored -- that shard is bad, but EVERY send still gets its receive: rank 0 goes on receiving
+        // (and discarding) the remaining pieces and shards, a sender whose read failed still sends the piece.  (Stopping rank 0's loop at an
+        // I/O error left ranks r + 1 .. in ncclSend with no receive coming: RCCL has no time-out, the job hung.)
+        bool comm_ok = true, io_failed = false;
         FILE* f = rank != 0 && !my_path.empty() ? fopen(my_path.c_str(), "rb") : nullptr;
         uint64_t my_size = 0;
-        if (f) { struct stat st {}; if (fstat(fileno(f), &st) == 0) my_size = (uint64_t)st.st_size; }
+        if (f) { struct stat st {}; if (fstat(fileno(f), &st) == 0) my_size = (uint64_t)st.st_size; else io_failed = true; }
+        else if (rank != 0 && !my_path.empty()) io_failed = true;     // a shard this rank says it has, and cannot open: never to be taken for transferred
+        if (io_failed) { my_size = 0; fprintf(stderr, "rank %d: cannot read its shard %s\n", rank, my_path.c_str()); }
         std::vector<uint64_t> sizes((size_t)world);
-        bool ok = allgather(&my_size, sizes.data(), 1) == 0;
+        comm_ok = allgather(&my_size, sizes.data(), 1) == 0;
         uint64_t biggest = 0;
         for (int r = 1; r < world; r++) biggest = std::max(biggest, sizes[(size_t)r]);
         const size_t piece = (size_t)std::min<uint64_t>(biggest, kPiece);
         void* d = nullptr; void* h = nullptr;
-        const bool need = ok && piece && (rank == 0 || my_size);
-        uint64_t ready = !ok ? 0 : !need ? 1 : (hipMalloc(&d, piece) == hipSuccess && hipHostMalloc(&h, piece, hipHostMallocDefault) == hipSuccess);
+        const bool need = comm_ok && piece && (rank == 0 || my_size);
+        uint64_t ready = !comm_ok ? 0 : !need ? 1 : (hipMalloc(&d, piece) == hipSuccess && hipHostMalloc(&h, piece, hipHostMallocDefault) == hipSuccess);
         std::vector<uint64_t> all_ready((size_t)world, 0);
-        if (ok) ok = allgather(&ready, all_ready.data(), 1) == 0;                     // (a rank whose first all-gather failed cannot be helped: the communicator is gone)
-        for (int r = 0; r < world && ok; r++) if (!all_ready[(size_t)r]) { ok = false; if (rank == 0) fprintf(stderr, "rank 0: rank %d has no staging memory for the shard gather\n", r); }
-        if (ok && piece) {
-            for (int r = 1; r < world && ok; r++) {
+        if (comm_ok) comm_ok = allgather(&ready, all_ready.data(), 1) == 0;           // (a rank whose first all-gather failed cannot be helped: the communicator is gone)
+        bool transfer = comm_ok && piece != 0;
+        for (int r = 0; r < world && comm_ok; r++) if (!all_ready[(size_t)r]) { transfer = false; io_failed = true; if (rank == 0) fprintf(stderr, "rank 0: rank %d has no staging memory for the shard gather\n", r); }
+        if (transfer) {
+            for (int r = 1; r < world && comm_ok; r++) {
                 const uint64_t total = sizes[(size_t)r];
                 if (!total || (rank != 0 && rank != r)) continue;
                 FILE* out = nullptr;
                 const std::string final_path = out_dir + "/compressed_" + std::to_string(r) + ".zwz", tmp_path = final_path + ".part";
                 if (rank == 0 && !(out = fopen(tmp_path.c_str(), "wb"))) fprintf(stderr, "rank 0: cannot create %s\n", tmp_path.c_str());
-                bool io_ok = rank != 0 || out != nullptr;
-                // (an I/O failure on either side does not stop the pieces: the peer is already committed to them; it marks the shard bad)
-                for (uint64_t off = 0; off < total; off += piece) {
+                bool shard_ok = rank != 0 || out != nullptr;
+                for (uint64_t off = 0; off < total && comm_ok; off += piece) {
                     const size_t k = (size_t)std::min<uint64_t>(piece, total - off);
                     if (rank == r) {
-                        if (io_ok && fread(h, 1, k, f) != k) io_ok = false;
-                        ok = hipMemcpyAsync(d, h, k, hipMemcpyHostToDevice, stream) == hipSuccess && ncclSend(d, k, ncclChar, 0, comm, stream) == ncclSuccess &&
-                             hipStreamSynchronize(stream) == hipSuccess && ok;
+                        if (shard_ok && fread(h, 1, k, f) != k) shard_ok = false;
+                        if (hipMemcpyAsync(d, h, k, hipMemcpyHostToDevice, stream) != hipSuccess) shard_ok = false;    // (the piece is sent all the same: rank 0 is waiting for it)
+                        comm_ok = ncclSend(d, k, ncclChar, 0, comm, stream) == ncclSuccess && hipStreamSynchronize(stream) == hipSuccess;
                     } else {
-                        ok = ncclRecv(d, k, ncclChar, r, comm, stream) == ncclSuccess && hipMemcpyAsync(h, d, k, hipMemcpyDeviceToHost, stream) == hipSuccess &&
-                             hipStreamSynchronize(stream) == hipSuccess && ok;
-                        if (ok && io_ok && fwrite(h, 1, k, out) != k) io_ok = false;
+                        comm_ok = ncclRecv(d, k, ncclChar, r, comm, stream) == ncclSuccess;
+                        if (comm_ok && hipMemcpyAsync(h, d, k, hipMemcpyDeviceToHost, stream) != hipSuccess) shard_ok = false;
+                        comm_ok = comm_ok && hipStreamSynchronize(stream) == hipSuccess;
+                        if (comm_ok && shard_ok && fwrite(h, 1, k, out) != k) shard_ok = false;       // (a full disk: this shard is lost, the next ones are still received)
                     }
-                    if (!ok) break;          // the communicator itself failed: nothing further can be matched
                 }
-                if (out) { if (fclose(out) != 0) io_ok = false; if (ok && io_ok) io_ok = rename(tmp_path.c_str(), final_path.c_str()) == 0; else unlink(tmp_path.c_str()); }
-                if (!io_ok) { fprintf(stderr, "rank %d: I/O error while %s shard %d\n", rank, rank == 0 ? "writing" : "reading", r); ok = false; }
+                if (out) { if (fclose(out) != 0) shard_ok = false; if (comm_ok && shard_ok) shard_ok = rename(tmp_path.c_str(), final_path.c_str()) == 0; else unlink(tmp_path.c_str()); }
+                if (!shard_ok) { fprintf(stderr, "rank %d: I/O error while %s shard %d\n", rank, rank == 0 ? "writing" : "reading", r); io_failed = true; }
             }
         }
         if (f) fclose(f);
         if (d) (void)hipFree(d);
         if (h) (void)hipHostFree(h);
         // every rank learns whether every transfer and every write succeeded (a sender must not delete a shard rank 0 could not store)
-        uint64_t fine = ok ? 1 : 0;
+        if (!comm_ok) return false;
+        uint64_t fine = io_failed ? 0 : 1;
         std::vector<uint64_t> all_fine((size_t)world, 0);
         if (allgather(&fine, all_fine.data(), 1) != 0) return false;
         for (int r = 0; r < world; r++) if (!all_fine[(size_t)r]) return false;

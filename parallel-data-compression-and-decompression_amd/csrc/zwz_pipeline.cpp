@@ -1039,7 +1039,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     const uint32_t j0 = (uint32_t)(T * (uint64_t)rank / (uint64_t)nranks), j1 = (uint32_t)(T * (uint64_t)(rank + 1) / (uint64_t)nranks);
     const uint32_t n = j1 - j0;
     uint8_t* d_big = nullptr; uint32_t* d_lens = nullptr; uint32_t* d_stat = nullptr;
-    std::vector<uint32_t> lens;
+    std::vector<uint32_t> lens, stats;      // decoded length and end-of-stream status of every chunk of the range (phase 1)
     Slices sl;
     bool have_slices = false;
     const uint32_t cap = std::max(1u, std::min(c->max_batch, std::min(kSliceChunks, n ? (n + 1) / 2 + 1 : 1u)));
@@ -1088,7 +1088,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
     };
     uint64_t mine[kFields] = {kNoFile, 0, kNoFile, 0, 0};
     shielded("inflating a record range", [&] {
-        lens.resize(n); fds.assign(insts.size(), -1); cursor.assign(insts.size(), 0);
+        lens.resize(n); stats.resize(n); fds.assign(insts.size(), -1); cursor.assign(insts.size(), 0);
         if (n && rc == ZWZ_OK) {
             hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_lens), (size_t)n * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_stat), (size_t)n * sizeof(uint32_t));
@@ -1126,6 +1126,7 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         pool.wait(fill_group[0]); pool.wait(fill_group[1]);
         if (rc == ZWZ_OK && n) {
             hipError_t e = hipMemcpyAsync(lens.data(), d_lens, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(stats.data(), d_stat, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) rc = hip_fail(e, "decoded lengths");
         }
@@ -1162,7 +1163,8 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
         for (uint32_t s = 0; s < nslices; s++) {
             const int b = (int)(s & 1u);
             const uint32_t g0 = s * cap, g1 = std::min(n, g0 + cap);
-            if (s >= 2) pool.wait(write_group);             // h_out[b] was the slice before last's: its writes must be through (waits for the last slice's too)
+            // (h_out[b] was the slice before last's; its writes were waited for in the last trip, before that trip's own were submitted -- a wait
+            //  here would also wait for the LAST slice's writes and serialise this slice's copy / second inflate behind them: ADVICE r4)
             hipError_t e = hipSuccess;
             if (g1 <= res) e = hipMemcpyAsync(sl.h_out[b], d_big + (size_t)g0 * ZWZ_DEV_STRIDE, (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
             else {
@@ -1171,11 +1173,16 @@ int decode_shard_split(zwz_ctx* c, Pool& pool, const Mapped& blob, std::vector<F
                 if (rc) break;
                 e = hipMemcpyAsync(sl.h_out[b], sl.d_out[b], (size_t)(g1 - g0) * ZWZ_DEV_STRIDE, hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.h_olen[b], sl.d_olen[b], (size_t)(g1 - g0) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.h_st[b], sl.d_st[b], (size_t)(g1 - g0) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc = hip_fail(e, "decoded range to host"); break; }
             if (g1 > res) {
-                for (uint32_t g = g0; g < g1; g++) if (sl.h_olen[b][g - g0] != lens[g]) { set_error("a chunk decoded to %u bytes the second time, %u the first", sl.h_olen[b][g - g0], lens[g]); rc = ZWZ_E_IO; }
+                // the second decode must be the first: same length, same status (how the stream ended) for every chunk
+                for (uint32_t g = g0; g < g1; g++) {
+                    if (sl.h_olen[b][g - g0] != lens[g]) { set_error("a chunk decoded to %u bytes the second time, %u the first", sl.h_olen[b][g - g0], lens[g]); rc = ZWZ_E_IO; }
+                    else if (sl.h_st[b][g - g0] != stats[g]) { set_error("a chunk's stream ended with status %u the second time, %u the first", sl.h_st[b][g - g0], stats[g]); rc = ZWZ_E_IO; }
+                }
                 if (rc) break;
                 if (s + 1 < nslices) { pool.wait(fill_group[(s + 1) & 1u]); start_fill(s + 1); }     // (h_in of the other pair is free: its slice is on the device or done)
             }

@@ -88,8 +88,11 @@ variant)   # <tag> "<compiler flags>" [bench.py args ...]: a build with other co
   TAG=${1:-v}; FL=$2; shift; shift
   make -C $PKG EXP_FLAGS="$FL" libzwz_hip_exp.so > $R/gpurun_out/exp_build.log 2>&1 || { echo "variant build failed"; tail -30 $R/gpurun_out/exp_build.log; exit 1; }
   cd $R && ZWZ_LIB=$PKG/libzwz_hip_exp.so timeout -k 10 600 python3 bench.py "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; rc=$?
-  tail -c 400 gpurun_out/bench_$TAG.err; echo "variant $FL:"; [ -s gpurun_out/bench_$TAG.json ] && bench_table gpurun_out/bench_$TAG.json   # (rc 3 = verification failed: expected of a timing-only experiment, the stage times still stand)
-  exit 0 ;;
+  tail -c 400 gpurun_out/bench_$TAG.err; echo "variant $FL: rc=$rc"; [ -s gpurun_out/bench_$TAG.json ] && bench_table gpurun_out/bench_$TAG.json
+  # rc 3 = verification failed: expected of a timing-only experiment, the stage times still stand.  Anything else -- a time-out (124 / 137), a
+  # crash, a GPU fault -- is a failure: a caller that chains variants with && must not launch the next one on this box.
+  [ $rc -eq 0 ] || [ $rc -eq 3 ] && exit 0
+  tail -40 gpurun_out/bench_$TAG.err; exit $rc ;;
 soak)
   TAG=${1:-s}; N=${2:-40000}; SEED=${3:-3}
   cd $R && timeout -k 10 900 python tools/soak_gpu.py $N $SEED > gpurun_out/soak_$TAG.log 2>&1 || { echo "soak failed"; tail -20 gpurun_out/soak_$TAG.log; exit 1; }
