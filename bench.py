@@ -378,33 +378,34 @@ def run_workload(args, torch, dist, codec, dev, world, rank, name):
         n_all = total // CHUNK + 1
         j0, j1 = n_all * rank // world, n_all * (rank + 1) // world
         n = j1 - j0
-        block, _, _, _, _, _ = workloads.build_equal_files(torch, cpu_dev, "text", 64, 1 << 20, 0, distinct_text=64)
-        flat_src = block.view(64 * 17, STRIDE)[:, :CHUNK]                     # text in 65 535-byte rows (last row of a file is short: skip those)
-        rows_host = flat_src[[i for i in range(64 * 17) if i % 17 != 16]].contiguous()        # 1024 full rows of text
-        rows = rows_host.to(dev)
+        # Every record its own text (Zipf words of one vocabulary, the sequence drawn from the record's seed: workloads.text_rows_device), generated
+        # on the device 2 048 records at a time; the file's last record is ragged (64 GiB = 1 048 592 x 65 535 + 16 bytes).  Rounds 3-4 tiled
+        # 1 024 distinct rows 1 024 times: equal lengths, perfect balance for a kernel that sorts its chunks by payload length.
         d_in = torch.zeros(n * STRIDE, dtype=torch.uint8, device=dev)
         view = d_in.view(n, STRIDE)
-        for c0 in range(0, n, 1024):
-            c1 = min(n, c0 + 1024)
-            view[c0:c1, :CHUNK] = rows[:c1 - c0]
+        seed0 = workloads.TEXT_SEED0 + 50_000_000
+        for c0 in range(0, n, 2048):
+            c1 = min(n, c0 + 2048)
+            view[c0:c1, :CHUNK] = workloads.text_rows_device(torch, list(range(seed0 + j0 + c0, seed0 + j0 + c1)), CHUNK, dev)
         lens = torch.full((n,), CHUNK, dtype=torch.int32, device=dev)
         if j1 == n_all:
             lens[-1] = total % CHUNK
+            view[-1, int(total % CHUNK):] = 0
         d_len, d_off = lens, torch.arange(n, dtype=torch.int64, device=dev) * STRIDE
         raw_bytes = int(d_len.sum().item())
         host_file, cpu_files = None, 0
         scaling = "strong"
         cpu_bytes = min(total, args.cpu_sample_one_file_bytes)
 
-        def populate(src):          # the file's first cpu_bytes bytes: the same 1 024 rows of text, in the same order
-            blob = rows_host.numpy().tobytes()
+        cpu_rows = min(n, (cpu_bytes + CHUNK - 1) // CHUNK)
+        head_host = view[:cpu_rows, :CHUNK].cpu().numpy()          # (rank 0's first records = the file's first bytes)
+
+        def populate(src):          # the file's first cpu_bytes bytes: the same records, in the same order
+            blob = head_host.tobytes()[:cpu_bytes]
             with open(os.path.join(src, "one.txt"), "wb") as f:
-                left = cpu_bytes
-                while left > 0:
-                    f.write(blob[:left])
-                    left -= min(left, len(blob))
-            return cpu_bytes
-        cpu_tree = (populate, "the file's first %d bytes (same rows of text) as ONE file -> one shard; the reference decodes a shard on one thread "
+                f.write(blob)
+            return len(blob)
+        cpu_tree = (populate, "the file's first %d bytes (the same records) as ONE file -> one shard; the reference decodes a shard on one thread "
                               "(decompression.cpp:165-178), so decompress_GBps is its single-thread rate whatever the file's size" % cpu_bytes, [1])
         desc = "ONE %.1f GB text-like file = %d records in one shard, split into %d contiguous record ranges (BASELINE configs[4] scaled: 64 GiB there)" % (total / 1e9, n_all, world)
     d_out = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)

@@ -148,3 +148,33 @@ def build_small_files(torch, dev, n_files, rank=0):
     d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
     d_off = torch.arange(n, dtype=torch.int64, device=dev) * STRIDE
     return d_in, d_off, d_len, n, int(sizes.sum()), lambda i: small_file_bytes(i, sizes[i], rank)
+
+
+def text_rows_device(torch, seeds, n_bytes, dev, vocab_seed=TEXT_SEED0, vocab=4096):
+    """corpus.text_like restated on the device for many rows at once: row r = the first n_bytes bytes of Zipf(1/rank) words over ONE
+    vocabulary (vocab_seed's: the words corpus.text_like(vocab_seed, .) draws from), the sequence of words drawn from seeds[r] -- every
+    row a different text of the same language.  -> (len(seeds), n_bytes) uint8.  (bench.py --workload one_file: distinct text per record,
+    where rounds 3-4 tiled 1 024 rows.)"""
+    wl = (corpus.splitmix64(vocab_seed ^ 0x1111, vocab) % np.uint64(7)).astype(np.int64) + 2
+    letters = (corpus.splitmix64(vocab_seed ^ 0x2222, int(wl.sum())) % np.uint64(26)).astype(np.uint8) + 97
+    starts = np.concatenate([[0], np.cumsum(wl)[:-1]])
+    p = 1.0 / np.arange(1, vocab + 1)
+    cdf = np.cumsum(p / p.sum())
+    t_wl = torch.from_numpy(wl).to(dev)
+    t_letters = torch.from_numpy(letters).to(dev)
+    t_starts = torch.from_numpy(starts).to(dev)
+    t_cdf = torch.from_numpy(cdf).to(dev)
+    k = len(seeds)
+    nwords = n_bytes // 3 + 8                                   # words are >= 3 bytes with their space
+    z = splitmix64_device(torch, torch.as_tensor(seeds, dtype=torch.int64) ^ 0x3333, nwords, dev)
+    u = _lsr(torch, z, 11).to(torch.float64) / float(1 << 53)
+    idx = torch.clamp(torch.searchsorted(t_cdf, u.reshape(-1)).view(k, nwords), max=vocab - 1)
+    del z, u
+    wlen = t_wl[idx]
+    pos = torch.cumsum(wlen + 1, dim=1) - (wlen + 1)            # where each word starts in its row
+    out = torch.full((k, n_bytes + 16), 32, dtype=torch.uint8, device=dev)
+    rows = torch.arange(k, device=dev).view(-1, 1).expand(k, nwords)
+    for j in range(8):
+        m = (wlen > j) & (pos + j < n_bytes)
+        out[rows[m], (pos + j)[m]] = t_letters[(t_starts[idx] + j)[m]]
+    return out[:, :n_bytes]
