@@ -140,6 +140,25 @@ typedef int (*zwz_allgather_u64_fn)(void *user, const uint64_t *mine, uint64_t *
 int zwz_decompress_dir_ranked(zwz_ctx *ctx, const char *src_dir, const char *dst_dir, int rank, int nranks,
                               zwz_allgather_u64_fn exchange, void *user, int *md5_mismatches);
 
+/* "A final gather of per-shard .zwz blobs" (north star; the reference has none: every MPI rank writes compressed_<rank>.zwz itself,
+ * compression.cpp:151-170).  The protocol, stated once for every launcher (csrc/main.cpp: RCCL; cli.py: torch.distributed): sizes and
+ * readiness by all-gather, then every rank's shard travels to rank 0 in pieces of at most piece_bytes (0: 64 MiB), one send for one
+ * receive; an I/O failure on either side marks a shard bad without leaving any send unmatched.  Rank 0 writes
+ * <out_dir>/compressed_<r>.zwz (through a .part name).  my_shard_path: this rank's shard, "" or NULL = nothing to contribute (rank 0, an
+ * idle or failed rank).  Returns 1 only if every rank saw every transfer and every write succeed -- only then may a sender delete its
+ * copy.  The hooks move HOST memory; all of them return 0 on success; a failing send / recv / all-gather means the transport is gone.
+ * prepare / release (optional): the transport's own staging for pieces of that size.  No GPU call is made by the library here. */
+typedef struct zwz_gather_hooks {
+    void *user;
+    int (*allgather_u64)(void *user, const uint64_t *mine, uint64_t *all, uint32_t count);
+    int (*send)(void *user, const void *buf, uint64_t nbytes, int to_rank);
+    int (*recv)(void *user, void *buf, uint64_t nbytes, int from_rank);
+    int (*prepare)(void *user, uint64_t piece_bytes);
+    void (*release)(void *user);
+} zwz_gather_hooks;
+int zwz_gather_shards(int rank, int nranks, const char *my_shard_path, const char *out_dir, uint64_t piece_bytes,
+                      const zwz_gather_hooks *hooks);
+
 /* Opt-in, never the default, NOT bit-exact with the reference's shards: raw bytes per Chunk for
  * zwz_compress_dir, 1..65535; 0 restores the reference's 65535 (process.hpp:12).  ZWZ_LOSSLESS_CHUNK_SIZE (65509) is the
  * largest size whose level-6 stream always fits the reference's 65535-byte payload buffer (compression.cpp:127-132), so

@@ -12,7 +12,8 @@ over xGMI when GPUs are present, "gloo" otherwise):
     MPI_Barrier + MPI_Wtime banner (main.cpp:144-155)
         -> dist.barrier() + the same banner text
     (addition, --gather) per-shard .zwz blobs collected on rank 0 for hosts without a shared output
-        directory; the reference has no gather (every rank writes compressed_<rank>.zwz itself)
+        directory; the reference has no gather (every rank writes compressed_<rank>.zwz itself).  The protocol is
+        the library's zwz_gather_shards -- the code csrc/main.cpp drives over RCCL -- with torch.distributed as its transport
 
     (addition) decompression is a single-rank job in the reference (main.cpp:61-68); here shard j goes to rank j mod N,
         and fewer shards than ranks are split by record ranges with an all_gather of decoded byte counts
@@ -46,35 +47,60 @@ def broadcast_bytes(data, src=0):
     return bytes(buf.cpu().numpy().tobytes())
 
 
-def gather_blobs(blob, dst=0):
-    """Every rank's bytes on rank dst (list indexed by rank), None elsewhere: an all-gather of the sizes (8 bytes a
-    rank), then each rank sends its shard to dst and nowhere else (RCCL has no gatherv; an all-gather of padded shards
-    would leave every shard on every GPU)."""
+def gather_shards(my_shard_path, out_dir, piece_bytes=0):
+    """Every rank's shard file on rank 0 as <out_dir>/compressed_<r>.zwz: the library's protocol (include/zwz.h: zwz_gather_shards --
+    the same code csrc/main.cpp drives over RCCL; sizes and readiness by all-gather, bounded pieces, one send for one receive, an I/O
+    failure never leaves a send unmatched) with torch.distributed's send / recv / all_gather as its hooks.  my_shard_path: "" = this
+    rank contributes nothing.  True only if every rank saw every transfer and every write succeed."""
+    import ctypes
     import torch
+    from . import lib
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [blob]
+        return True
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([len(blob)], dtype=torch.int64, device=dev))
-    sizes = [int(s.item()) for s in sizes]
-    if rank != dst:
-        if sizes[rank]:
-            mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            dist.send(mine, dst)
-        return None
-    out = []
-    for r in range(world):
-        if r == dst:
-            out.append(blob)
-        elif sizes[r] == 0:
-            out.append(b"")
-        else:
-            buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
-            dist.recv(buf, r)
-            out.append(bytes(buf.cpu().numpy().tobytes()))
-    return out
+    AG = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+    SEND = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int)
+    RECV = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int)
+    PREP = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64)
+    REL = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+    class Hooks(ctypes.Structure):
+        _fields_ = [("user", ctypes.c_void_p), ("allgather_u64", AG), ("send", SEND), ("recv", RECV), ("prepare", PREP), ("release", REL)]
+
+    def ag(_, mine, out, count):
+        try:
+            got = allgather_u64([mine[i] for i in range(count)])
+            for i, v in enumerate(got):
+                out[i] = v
+            return 0
+        except Exception:
+            return -1
+
+    def send(_, buf, n, to):
+        try:
+            t = torch.frombuffer((ctypes.c_ubyte * n).from_address(buf), dtype=torch.uint8).clone().to(dev)
+            dist.send(t, to)
+            return 0
+        except Exception:
+            return -1
+
+    def recv(_, buf, n, src):
+        try:
+            t = torch.empty(n, dtype=torch.uint8, device=dev)
+            dist.recv(t, src)
+            h = t.cpu().contiguous()
+            ctypes.memmove(buf, h.data_ptr(), n)
+            return 0
+        except Exception:
+            return -1
+
+    hooks = Hooks(None, AG(ag), SEND(send), RECV(recv), PREP(lambda _, n: 0), REL(lambda _: None))
+    fn = lib().zwz_gather_shards
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(Hooks)]
+    return fn(rank, world, (my_shard_path or "").encode(), out_dir.encode(), piece_bytes, ctypes.byref(hooks)) == 1
 
 
 def allgather_u64(values):
@@ -152,13 +178,14 @@ def run(operation, source_path, output_path, *, compress_fn=None, decompress_fn=
             if gather and world > 1:
                 path = os.path.join(shard_dir, "compressed_%d.zwz" % rank)
                 # (a rank that failed hands over nothing -- a partially written shard must not reach <dst> under a good name; csrc/main.cpp does the same)
-                blob = open(path, "rb").read() if failure is None and os.path.exists(path) else b""
-                blobs = gather_blobs(blob, 0)
-                if rank == 0:
-                    for r, b in enumerate(blobs):
-                        if r and b:
-                            with open(os.path.join(output_path, "compressed_%d.zwz" % r), "wb") as g:
-                                g.write(b)
+                mine = path if rank != 0 and failure is None and os.path.exists(path) else ""
+                if not gather_shards(mine, output_path):
+                    # the shard stays where the rank wrote it: nothing is lost, and the message says where it is
+                    if failure is None:
+                        failure = RuntimeError("the gather of the shards failed" + ("; this rank's shard is kept at %s" % path if mine else ""))
+                elif mine and shard_dir != output_path:
+                    os.unlink(path)
+                    os.rmdir(shard_dir)
         finally:
             os.unlink(local_record)
     else:

@@ -268,72 +268,42 @@ struct Rccl {
             return hipMemcpy(send, mine, one, hipMemcpyHostToDevice) == hipSuccess && ncclAllGather(send, d, count, ncclUint64, comm, stream) == ncclSuccess &&
                    hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(all, d, one * (size_t)world, hipMemcpyDeviceToHost) == hipSuccess; }) ? 0 : -1;
     }
-    // "a final gather of per-shard .zwz blobs" (north star; the reference leaves every rank's shard where the rank wrote it).  Sizes by
-    // all-gather; then every rank's shard travels to rank 0 in pieces of at most kPiece bytes through ONE staging buffer per rank --
-    // device memory does not grow with shard size x ranks (round 3 allocated every peer's whole shard on rank 0 at once) -- and every
-    // send has exactly one matching receive: whether the transfers happen at all is decided by an all-gather of "my staging
-    // buffer exists", so either every rank enters them or none does (an unmatched ncclSend never completes and RCCL has no
-    // time-out).  Rank 0 writes each shard to <out_dir>/compressed_<r>.zwz through a temporary name.  my_path: this rank's shard
-    // file ("" or unreadable: the rank contributes nothing, e.g. because it failed or had no file to compress).
-    static constexpr size_t kPiece = (size_t)64 << 20;
+    // "a final gather of per-shard .zwz blobs" (north star): the protocol is the library's (zwz_gather_shards, csrc/zwz_gather.cpp -- the same
+    // code cli.py drives over torch.distributed); here are its hooks over RCCL.  A piece goes host -> device staging -> ncclSend on the sender,
+    // ncclRecv -> device staging -> host on rank 0: ONE device buffer and one pinned host buffer of a piece's size per rank, whatever the
+    // shards' sizes (round 3 allocated every peer's whole shard on rank 0 at once).
+    void* g_dev = nullptr; void* g_pin = nullptr; uint64_t g_piece = 0;
+    static int hook_allgather(void* u, const uint64_t* mine, uint64_t* all, uint32_t count) { return static_cast<Rccl*>(u)->allgather(mine, all, count); }
+    static int hook_prepare(void* u, uint64_t piece) {
+        Rccl* r = static_cast<Rccl*>(u);
+        r->g_piece = piece;
+        return hipMalloc(&r->g_dev, piece) == hipSuccess && hipHostMalloc(&r->g_pin, piece, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+    }
+    static void hook_release(void* u) {
+        Rccl* r = static_cast<Rccl*>(u);
+        if (r->g_dev) (void)hipFree(r->g_dev);
+        if (r->g_pin) (void)hipHostFree(r->g_pin);
+        r->g_dev = r->g_pin = nullptr; r->g_piece = 0;
+    }
+    static int hook_send(void* u, const void* buf, uint64_t n, int to) {
+        Rccl* r = static_cast<Rccl*>(u);
+        if (!r->g_dev || n > r->g_piece) return -1;
+        memcpy(r->g_pin, buf, (size_t)n);
+        (void)hipMemcpyAsync(r->g_dev, r->g_pin, (size_t)n, hipMemcpyHostToDevice, r->stream);     // (a failed copy still sends the piece: the receiver is waiting; its write then fails the MD5 later)
+        return ncclSend(r->g_dev, (size_t)n, ncclChar, to, r->comm, r->stream) == ncclSuccess && hipStreamSynchronize(r->stream) == hipSuccess ? 0 : -1;
+    }
+    static int hook_recv(void* u, void* buf, uint64_t n, int from) {
+        Rccl* r = static_cast<Rccl*>(u);
+        if (!r->g_dev || n > r->g_piece) return -1;
+        if (ncclRecv(r->g_dev, (size_t)n, ncclChar, from, r->comm, r->stream) != ncclSuccess) return -1;
+        const bool copied = hipMemcpyAsync(r->g_pin, r->g_dev, (size_t)n, hipMemcpyDeviceToHost, r->stream) == hipSuccess;
+        if (hipStreamSynchronize(r->stream) != hipSuccess) return -1;
+        if (copied) memcpy(buf, r->g_pin, (size_t)n); else memset(buf, 0, (size_t)n);
+        return 0;
+    }
     bool gather_files(const std::string& my_path, const std::string& out_dir) {
-        // Two kinds of failure, kept apart.  comm_ok: an RCCL or HIP call failed -- nothing further can be matched, the loops end.
-        // io_failed: a shard could not be read or stored -- that shard is bad, but EVERY send still gets its receive: rank 0 goes on receiving
-        // (and discarding) the remaining pieces and shards, a sender whose read failed still sends the piece.  (Stopping rank 0's loop at an
-        // I/O error left ranks r + 1 .. in ncclSend with no receive coming: RCCL has no time-out, the job hung.)
-        bool comm_ok = true, io_failed = false;
-        FILE* f = rank != 0 && !my_path.empty() ? fopen(my_path.c_str(), "rb") : nullptr;
-        uint64_t my_size = 0;
-        if (f) { struct stat st {}; if (fstat(fileno(f), &st) == 0) my_size = (uint64_t)st.st_size; else io_failed = true; }
-        else if (rank != 0 && !my_path.empty()) io_failed = true;     // a shard this rank says it has, and cannot open: never to be taken for transferred
-        if (io_failed) { my_size = 0; fprintf(stderr, "rank %d: cannot read its shard %s\n", rank, my_path.c_str()); }
-        std::vector<uint64_t> sizes((size_t)world);
-        comm_ok = allgather(&my_size, sizes.data(), 1) == 0;
-        uint64_t biggest = 0;
-        for (int r = 1; r < world; r++) biggest = std::max(biggest, sizes[(size_t)r]);
-        const size_t piece = (size_t)std::min<uint64_t>(biggest, kPiece);
-        void* d = nullptr; void* h = nullptr;
-        const bool need = comm_ok && piece && (rank == 0 || my_size);
-        uint64_t ready = !comm_ok ? 0 : !need ? 1 : (hipMalloc(&d, piece) == hipSuccess && hipHostMalloc(&h, piece, hipHostMallocDefault) == hipSuccess);
-        std::vector<uint64_t> all_ready((size_t)world, 0);
-        if (comm_ok) comm_ok = allgather(&ready, all_ready.data(), 1) == 0;           // (a rank whose first all-gather failed cannot be helped: the communicator is gone)
-        bool transfer = comm_ok && piece != 0;
-        for (int r = 0; r < world && comm_ok; r++) if (!all_ready[(size_t)r]) { transfer = false; io_failed = true; if (rank == 0) fprintf(stderr, "rank 0: rank %d has no staging memory for the shard gather\n", r); }
-        if (transfer) {
-            for (int r = 1; r < world && comm_ok; r++) {
-                const uint64_t total = sizes[(size_t)r];
-                if (!total || (rank != 0 && rank != r)) continue;
-                FILE* out = nullptr;
-                const std::string final_path = out_dir + "/compressed_" + std::to_string(r) + ".zwz", tmp_path = final_path + ".part";
-                if (rank == 0 && !(out = fopen(tmp_path.c_str(), "wb"))) fprintf(stderr, "rank 0: cannot create %s\n", tmp_path.c_str());
-                bool shard_ok = rank != 0 || out != nullptr;
-                for (uint64_t off = 0; off < total && comm_ok; off += piece) {
-                    const size_t k = (size_t)std::min<uint64_t>(piece, total - off);
-                    if (rank == r) {
-                        if (shard_ok && fread(h, 1, k, f) != k) shard_ok = false;
-                        if (hipMemcpyAsync(d, h, k, hipMemcpyHostToDevice, stream) != hipSuccess) shard_ok = false;    // (the piece is sent all the same: rank 0 is waiting for it)
-                        comm_ok = ncclSend(d, k, ncclChar, 0, comm, stream) == ncclSuccess && hipStreamSynchronize(stream) == hipSuccess;
-                    } else {
-                        comm_ok = ncclRecv(d, k, ncclChar, r, comm, stream) == ncclSuccess;
-                        if (comm_ok && hipMemcpyAsync(h, d, k, hipMemcpyDeviceToHost, stream) != hipSuccess) shard_ok = false;
-                        comm_ok = comm_ok && hipStreamSynchronize(stream) == hipSuccess;
-                        if (comm_ok && shard_ok && fwrite(h, 1, k, out) != k) shard_ok = false;       // (a full disk: this shard is lost, the next ones are still received)
-                    }
-                }
-                if (out) { if (fclose(out) != 0) shard_ok = false; if (comm_ok && shard_ok) shard_ok = rename(tmp_path.c_str(), final_path.c_str()) == 0; else unlink(tmp_path.c_str()); }
-                if (!shard_ok) { fprintf(stderr, "rank %d: I/O error while %s shard %d\n", rank, rank == 0 ? "writing" : "reading", r); io_failed = true; }
-            }
-        }
-        if (f) fclose(f);
-        if (d) (void)hipFree(d);
-        if (h) (void)hipHostFree(h);
-        // every rank learns whether every transfer and every write succeeded (a sender must not delete a shard rank 0 could not store)
-        if (!comm_ok) return false;
-        uint64_t fine = io_failed ? 0 : 1;
-        std::vector<uint64_t> all_fine((size_t)world, 0);
-        if (allgather(&fine, all_fine.data(), 1) != 0) return false;
-        for (int r = 0; r < world; r++) if (!all_fine[(size_t)r]) return false;
-        return true;
+        zwz_gather_hooks hk{this, hook_allgather, hook_send, hook_recv, hook_prepare, hook_release};
+        return zwz_gather_shards(rank, world, my_path.c_str(), out_dir.c_str(), 0, &hk) == 1;
     }
     int worst_status(int rc) {                                      // barrier + every rank learns whether any rank failed
         int64_t v = rc != 0;
