@@ -296,6 +296,18 @@ def e2e_legs(args):
             out[nm] = e2e_tool.summarize(e2e_tool.measure(nm, n, False))
         if args.e2e_scale and args.e2e_scale > 1:
             out["text_x%d" % args.e2e_scale] = e2e_tool.summarize(e2e_tool.measure("text", n * args.e2e_scale, False))
+        # the same text directory on a memory file system, if the box has one: file creation there is not the overlay's (10 000 creates in
+        # one directory cost `main decompress` 0.1 - 1.5 s on the box's overlay root, run to run)
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and not (args.e2e_tmp or os.environ.get("ZWZ_E2E_TMP", "")).startswith("/dev/shm"):
+            keep = os.environ.get("ZWZ_E2E_TMP")
+            os.environ["ZWZ_E2E_TMP"] = "/dev/shm"
+            try:
+                out["text_tmpfs"] = e2e_tool.summarize(e2e_tool.measure("text", n, False))
+            finally:
+                if keep is None:
+                    os.environ.pop("ZWZ_E2E_TMP", None)
+                else:
+                    os.environ["ZWZ_E2E_TMP"] = keep
         out["note"] = ("the drop-in CLI end to end, one GPU, one process: raw bytes / the banner's seconds; steady_* = the pipelined slices alone, "
                        "fixed_s = process + HIP start-up, context self-tests, enumeration + sort, pinning, teardown (from a second, ZWZ_TIMELINE run)")
     except Exception as e:
