@@ -198,6 +198,10 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         __syncthreads();
         // ranking: positions in order, 64 a step, by ONE wave: the returning add hands same-bucket lanes their slots in lane order
         // (= position order), steps follow one another in program order.
+        // (Round 5, measured and dropped: ALL FOUR waves ranking, each the positions whose bucket lies in its quarter of the table -- buckets do not
+        // care about each other, so it is exact (all oracle tests passed) -- on the idea that the step is latency over what is in flight: links stage
+        // 7.1 -> 10.4 ms on text.  Every wave then loads all the hashes, and the per-lane guards around add and store are the exec-mask bookkeeping
+        // the unguarded trips below got rid of.)
         if (wave == 0) {
             // Whole trips of eight steps run without a single test (every lane has a position: guarded per lane, the loop was
             // mostly exec-mask bookkeeping); the next trip's hashes are on their way while this one ranks.
