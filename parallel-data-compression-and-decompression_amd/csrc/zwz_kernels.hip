@@ -1544,29 +1544,38 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     ZWZ_ESTAMP(0);                                            // ticket, masks, match ranks, codes, the stream's layout (thread 0)
     {   // the staging buffer, zeroed as far as this chunk's stream reaches (a whole 64 KiB per chunk was most of what a
         // 4-byte chunk cost: the 10 000 tail chunks of BASELINE configs[1] took 0.2 ms)
-        const uint32_t nz = min(kOutWords, (s_total_bytes + 3u) / 4u + 2u);
+        // (a chunk of one Huffman block is packed at private slots first -- below -- which reach as far as seven bits a position)
+        const bool slots = ci.n_blocks == 1u && s_blk[0].type != kStored;
+        const uint32_t reach = slots ? ((s_blk[0].body_pos + 63u) >> 5) + (kEncodeThreads / 64u) * ((wpw * 64u * 7u + 31u) >> 5) + 2u : 0u;
+        const uint32_t nz = min(kOutWords, max((s_total_bytes + 3u) / 4u + 2u, reach));
         for (uint32_t i = tid; i < nz; i += kEncodeThreads) s_out[i] = 0;
     }
     __syncthreads();
 
-    if (tid == 0) lds_or_bits(s_out, 0, 0x9c78u, 16);
-    for (uint32_t b = 0; b < ci.n_blocks; b++) {
-        const EncBlock e = s_blk[b];
-        const uint32_t hw = (bo[b].hdr_bits + 31) >> 5;
-        if (tid < hw) {
-            uint32_t nb = bo[b].hdr_bits - (tid << 5); if (nb > 32) nb = 32;
-            uint32_t v = bo[b].hdr[tid]; if (nb < 32) v &= (1u << nb) - 1u;
-            lds_or_bits(s_out, (uint64_t)e.hdr_pos + (tid << 5), v, nb);
-        }
-        if (tid == 0) {
-            if (e.type == kStored) {
-                const uint32_t len = e.end - e.start;
-                lds_or_bits(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
-            } else {
-                lds_or_bits(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
+    // A chunk that is ONE Huffman block (text: 13.6 k symbols a chunk, under the 16 383 of a block) is packed in a single pass over its symbols
+    // (round 5; see the symbols' block below): the stream's fixed parts then go in behind the symbols, whose waves use the buffer as scratch first.
+    const bool one_pass = ci.n_blocks == 1u && s_blk[0].type != kStored && (ZWZ_ENC_EXP & 1) == 0;       // workgroup-uniform
+    auto write_headers = [&]() {
+        if (tid == 0) lds_or_bits(s_out, 0, 0x9c78u, 16);
+        for (uint32_t b = 0; b < ci.n_blocks; b++) {
+            const EncBlock e = s_blk[b];
+            const uint32_t hw = (bo[b].hdr_bits + 31) >> 5;
+            if (tid < hw) {
+                uint32_t nb = bo[b].hdr_bits - (tid << 5); if (nb > 32) nb = 32;
+                uint32_t v = bo[b].hdr[tid]; if (nb < 32) v &= (1u << nb) - 1u;
+                lds_or_bits(s_out, (uint64_t)e.hdr_pos + (tid << 5), v, nb);
+            }
+            if (tid == 0) {
+                if (e.type == kStored) {
+                    const uint32_t len = e.end - e.start;
+                    lds_or_bits(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
+                } else {
+                    lds_or_bits(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
+                }
             }
         }
-    }
+    };
+    if (!one_pass) write_headers();
 
     ZWZ_ESTAMP(1);                                            // staging zeroed, block headers
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
@@ -1654,6 +1663,65 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         };
 
         ZWZ_ESTAMP(2);                                        // Adler partials, stored blocks' bytes
+        // One Huffman block: ONE pass.  A wave does not know where its segment's bits start before every wave in front of it has added
+        // up its code lengths -- rounds 1-4 made a first pass over the symbols for that sum alone (28 % of the kernel: every byte and
+        // every chosen record fetched twice).  Here a wave packs its segment at a PRIVATE place first -- a slot of seven bits a position
+        // in the same staging buffer (a segment of text needs three) -- then, the wave totals known, reads its slot into registers, clears
+        // it, and ORs the words back shifted to where they belong.  A wave whose segment outgrows its slot sends the chunk through the two
+        // passes below (never on the corpora).
+        bool two_pass = !one_pass;
+        if (one_pass) {
+            const uint32_t slot_bits = (wpw * 64u * 7u + 31u) & ~31u, slot0 = (s_blk[0].body_pos + 63u) & ~31u;
+            const uint32_t q = slot0 + wave * slot_bits;                                       // a multiple of 32
+            uint32_t running = 0;
+            for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
+                uint64_t v = 0; uint32_t nb = 0;
+                if (live) symbol_bits(s_lcode, s_llen, s_dcode, s_dlen, rec, byte, v, nb);
+                const uint32_t incl = wave_scan_incl(nb);
+                if (nb) lds_or_bits(s_out, (uint64_t)q + (running + incl - nb), v, nb);
+                running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            });
+            if (lane == 0) s_wsum[wave] = running;
+            ZWZ_ESTAMP(3);
+            __syncthreads();
+            ZWZ_ESTAMP(4);
+            uint32_t before = 0; bool fits = true;
+            for (uint32_t i = 0; i < kEncodeThreads / 64u; i++) { const uint32_t m = s_wsum[i]; before += i < wave ? m : 0u; fits = fits && m <= slot_bits; }
+            fits = fits && slot0 + (kEncodeThreads / 64u) * slot_bits + 64u <= kOutWords * 32u;  // (the slots themselves fit the buffer)
+            if (fits) {
+                // The slots lie at or behind where their bits belong (slot0 >= body_pos, a wave's bits <= its slot), so they move in place, FOUR slots
+                // a turn by the whole workgroup (256 threads a slot, four words each): read and cleared, a barrier, ORed back at their destination
+                // -- words of these four slots (clear now) or of slots moved in earlier turns.  (First form: a wave moved its own slot, the waves
+                // in turn -- sixteen barriers with one wave working: the move cost as much as the pass it replaced.  Fourteen words a lane held
+                // across ONE barrier went to scratch under this kernel's 64 registers: 216 bytes a lane.)
+                if (tid < kEncodeThreads / 64u) { uint32_t pre = 0; for (uint32_t i = 0; i < tid; i++) pre += s_wsum[i]; s_msum[tid] = pre; }   // (s_msum: the match prefixes are in registers)
+                __syncthreads();
+                const uint32_t slot_words = slot_bits >> 5, u = tid & 255u;
+#pragma unroll 1
+                for (uint32_t turn = 0; turn < 4u; turn++) {
+                    const uint32_t sw = turn * 4u + (tid >> 8);                              // the slot this thread works on
+                    const uint32_t nw = (s_wsum[sw] + 31u) >> 5, base = (slot0 >> 5) + sw * slot_words;
+                    uint32_t w[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; w[k] = i < nw ? s_out[base + i] : 0u; }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; if (i < nw) s_out[base + i] = 0u; }
+                    __syncthreads();
+                    const uint64_t dst = (uint64_t)s_blk[0].body_pos + s_msum[sw];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; if (w[k]) lds_or_bits(s_out, dst + 32ull * i, w[k], 32); }
+                    __syncthreads();
+                }
+                write_headers();
+            } else {
+                two_pass = true;                                                               // workgroup-uniform: s_wsum is everybody's
+                __syncthreads();
+                for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
+                __syncthreads();
+                write_headers();
+            }
+        }
+      if (two_pass) {
         uint32_t mine = 0;
         for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
             if (live) {
@@ -1662,6 +1730,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             }
         });
         for (uint32_t d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        __syncthreads();                                      // (s_wsum may still be read by the one-pass attempt's check)
         if (lane == 0) s_wsum[wave] = mine;
         ZWZ_ESTAMP(3);                                        // first pass: code lengths
         __syncthreads();
@@ -1682,6 +1751,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             }
             running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         });
+      }
     }
 
     ZWZ_ESTAMP(5);                                            // second pass: bits into the staging buffer

@@ -97,6 +97,30 @@ def test_plan_stage_skewed_histograms(zwz, oracle, mode):
     codec.close()
 
 
+def test_encode_single_block_chunks_whose_bits_outgrow_the_private_slots(codec, oracle):
+    """encode packs a chunk of ONE Huffman block in a single pass: every wave at a private slot of seven bits a position, then the slots are
+    shifted into place (csrc/zwz_kernels.hip, round 5).  Data that a dynamic block codes at MORE than seven bits a symbol -- 150 to 250
+    equiprobable byte values, few enough bytes for one block -- outgrows the slots and must come out of the two-pass fallback the same;
+    so must chunks right at the edge (around 128 symbols: 7 bits), short chunks whose sixteen waves hold a word each, and chunks whose
+    segments are lopsided (text in front, dense bytes behind)."""
+    rs = np.random.RandomState(4711)
+    chunks = []
+    for nsym in (100, 120, 128, 136, 150, 180, 220, 250, 256):
+        for n in (900, 4000, 12000, 16000):
+            syms = rs.choice(256, nsym, replace=False)
+            chunks.append(syms[rs.randint(0, nsym, n)].astype(np.uint8).tobytes())
+    for n in (6000, 14000):
+        dense = rs.choice(256, 200, replace=False)[rs.randint(0, 200, n // 2)].astype(np.uint8).tobytes()
+        chunks.append(corpus.text_like(31337 + n, n // 2) + dense)
+        chunks.append(dense + corpus.text_like(31338 + n, n // 2))
+    got = codec.deflate_chunks(chunks)
+    for i, (c, g) in enumerate(zip(chunks, got)):
+        assert g == oracle.payload(c), (i, len(c))
+    back, _ = codec.inflate_chunks(got)
+    for c, b in zip(chunks, back):
+        assert b == c
+
+
 @pytest.mark.parametrize("flavour", ["band", "lazy"])
 def test_band_path_fuzz_every_kind_and_collision_heavy_data(zwz, oracle, flavour):
     """Every chunk through lz_sort + lz_place + lz_match_band (option match=band) / + lz_lazy (match=lazy), on what the production choice would never send there
