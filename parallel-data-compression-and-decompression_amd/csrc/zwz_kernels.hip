@@ -1290,6 +1290,17 @@ static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpo
     if (w + 2 < kOutWords && hi) atomicOr(&out[w + 2], hi);
 }
 
+// encode's private slots (one Huffman block, one pass): a wave packs its wpw words of positions at slot0 + wave * slot_bits first.  Twice a
+// wave's share of the block's bits (plan knows them), at most nine bits a position, or what the staging buffer has when that is less (a full chunk: 7.98 -- a Huffman chunk is smaller than its bytes as a whole, a
+// wave's segment need not be: then the chunk takes the two passes).  (Seven bits a position, the first form, sent most image-like chunks --
+// literals at 7+ bits -- through the attempt AND the two passes: configs[3]-shaped files 22.2 -> 33.7 ms.)
+static __device__ __forceinline__ uint32_t enc_slot_bits(uint32_t wpw, uint32_t body_pos, uint32_t body_bits) {
+    const uint32_t slot0 = (body_pos + 63u) & ~31u, nine = wpw * 64u * 9u, twice = 2u * (body_bits / (kEncodeThreads / 64u)) + 1024u;
+    const uint32_t want = nine < twice ? nine : twice;                      // (the buffer is zeroed as far as the slots reach: no wider than need be)
+    const uint32_t have = kOutWords * 32u > slot0 + 64u ? (kOutWords * 32u - 64u - slot0) / (kEncodeThreads / 64u) : 0u;
+    return (want < have ? want : have) & ~31u;
+}
+
 // An incompressible chunk: every block is stored, so the stream is the input with a 2-byte zlib
 // header, a 5-byte header in front of each block and the Adler-32 behind.  No staging: one pass
 // over the input for the checksum (v_dot4 sums four bytes per instruction; skipped when the cap cuts
@@ -1467,7 +1478,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
     uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
     __shared__ EncBlock s_blk[kMaxBlocks];
-    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_msum[kEncodeThreads / 64];
+    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_msum[kEncodeThreads / 64 + 1];
     __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
     __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
 
@@ -1544,9 +1555,9 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     ZWZ_ESTAMP(0);                                            // ticket, masks, match ranks, codes, the stream's layout (thread 0)
     {   // the staging buffer, zeroed as far as this chunk's stream reaches (a whole 64 KiB per chunk was most of what a
         // 4-byte chunk cost: the 10 000 tail chunks of BASELINE configs[1] took 0.2 ms)
-        // (a chunk of one Huffman block is packed at private slots first -- below -- which reach as far as seven bits a position)
+        // (a chunk of one Huffman block is packed at private slots first -- below -- whose reach is enc_slot_bits')
         const bool slots = ci.n_blocks == 1u && s_blk[0].type != kStored;
-        const uint32_t reach = slots ? ((s_blk[0].body_pos + 63u) >> 5) + (kEncodeThreads / 64u) * ((wpw * 64u * 7u + 31u) >> 5) + 2u : 0u;
+        const uint32_t reach = slots ? ((s_blk[0].body_pos + 63u) >> 5) + (kEncodeThreads / 64u) * (enc_slot_bits(wpw, s_blk[0].body_pos, s_blk[0].body_bits) >> 5) + 2u : 0u;
         const uint32_t nz = min(kOutWords, max((s_total_bytes + 3u) / 4u + 2u, reach));
         for (uint32_t i = tid; i < nz; i += kEncodeThreads) s_out[i] = 0;
     }
@@ -1555,7 +1566,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     // A chunk that is ONE Huffman block (text: 13.6 k symbols a chunk, under the 16 383 of a block) is packed in a single pass over its symbols
     // (round 5; see the symbols' block below): the stream's fixed parts then go in behind the symbols, whose waves use the buffer as scratch first.
     const bool one_pass = ci.n_blocks == 1u && s_blk[0].type != kStored && (ZWZ_ENC_EXP & 1) == 0;       // workgroup-uniform
-    auto write_headers = [&]() {
+    auto write_headers = [&](bool with_eob) {
         if (tid == 0) lds_or_bits(s_out, 0, 0x9c78u, 16);
         for (uint32_t b = 0; b < ci.n_blocks; b++) {
             const EncBlock e = s_blk[b];
@@ -1569,13 +1580,15 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
                 if (e.type == kStored) {
                     const uint32_t len = e.end - e.start;
                     lds_or_bits(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
-                } else {
+                } else if (with_eob) {
                     lds_or_bits(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
                 }
             }
         }
     };
-    if (!one_pass) write_headers();
+    write_headers(!one_pass);                                 // (one pass: the headers lie in front of the first slot; the end-of-block code joins on the way out)
+    bool in_slots = false;                                    // workgroup-uniform: the symbols' bits are still in the waves' slots when the stream goes out
+    uint32_t pre_l = 0;                                       // .. and lane i <= 16 holds the bits in front of wave i's
 
     ZWZ_ESTAMP(1);                                            // staging zeroed, block headers
     uint32_t a_sum = 0; unsigned long long b_sum = 0;   // Adler partials over this thread's bytes
@@ -1625,53 +1638,98 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         // or before it (holds for covered positions too: a block ends where its last symbol ends)
         const uint32_t b1 = ci.n_blocks > 1 ? s_blk[1].start : 0xffffffffu, b2 = ci.n_blocks > 2 ? s_blk[2].start : 0xffffffffu;
         const uint32_t b3 = ci.n_blocks > 3 ? s_blk[3].start : 0xffffffffu, b4 = ci.n_blocks > 4 ? s_blk[4].start : 0xffffffffu;
-        auto word_of = [&](uint64_t v, uint32_t it) -> uint64_t {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, it);          // the builtin returns int:
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), it);  // widen only after the cast
-            return (uint64_t)lo | ((uint64_t)hi << 32);
-        };
         auto block_of = [&](uint32_t p) { return (uint32_t)(p >= b1) + (uint32_t)(p >= b2) + (uint32_t)(p >= b3) + (uint32_t)(p >= b4); };
         const uint32_t trips = (seg_end > seg ? seg_end - seg + 63u : 0u) >> 6;
-        uint32_t* queue = s_queue + wave * kEncQueue;
-        // entry: position | index into `chosen` << 16 | match flag << 31
-        auto for_each_trip = [&](auto&& work) {                            // work(entry, byte, record, live) for every trip of <= 64 symbol starts, in stream order
-            uint32_t head = 0, tail = 0;                                   // wave-uniform: queue[head, tail) is waiting
-            uint32_t p_ent = 0, p_byte = 0, p_rec = 0, p_n = 0;            // the trip whose operands are in flight
-            auto take = [&](uint32_t n) {                                  // fetch for n waiting entries, then work on the trip taken before
-                const uint32_t ent = queue[(head + lane) & (kEncQueue - 1u)];       // (lanes >= n: stale entries, masked by `live`)
-                const bool live = lane < n;
-                const uint32_t byte = live ? (uint32_t)data[ent & 0xffffu] : 0u;
-                const uint32_t rec = live && (ent >> 31) ? chosen[(ent >> 16) & 0x7fffu] : 0u;   // dense: 4 bytes per match
-                head += n;
-                if (p_n) work(p_ent, p_byte, p_rec, lane < p_n);
-                p_ent = ent; p_byte = byte; p_rec = rec; p_n = n;
+        uint16_t* queue = reinterpret_cast<uint16_t*>(s_queue + wave * kEncQueue);
+        constexpr uint32_t kCap = 2u * kEncQueue;                           // 16-bit entries: position inside the segment (12 bits) | match flag << 15
+        // The queue is filled FOUR LANES A WORD: lane l takes quarter l & 3 of word next + (l >> 2) -- sixteen bits of both masks, fetched
+        // from the lanes that hold the words -- and writes out its symbol starts one a turn, behind those of the lanes in front of it (a scan
+        // of the quarters' counts).  On text a quarter holds three starts: a round of sixteen words is ~7 turns of a dozen instructions for ~200
+        // starts; where the words are nearly all starts (few matches: image-like data) they are not queued at all.  (Rounds 3 - 5 took the words one at a time -- five readlanes, ranks among the word's starts, the entry: 35 instructions a
+        // word, 175 a trip of 64 starts on text, more than the trip's own work.)  As many whole words go in as the queue has room for: at
+        // least three (fewer than 64 entries wait when a round starts).
+        // (Measured and dropped: ONE call site of work() an instantiation and nothing unrolled -- the kernel's code falls from 52 KB to 26 KB, on the idea
+        // that the once-a-chunk pieces behind barriers run out of a cold instruction cache: text 5.68 -> 6.39 ms.)
+        auto for_each_trip = [&](auto&& work) {                            // work(position, byte, record, live) for every trip of <= 64 symbol starts, in stream order
+            uint32_t head = 0, tail = 0, next = 0;                         // wave-uniform: queue[head, tail) is waiting; words [0, next) are in
+            uint32_t m_run = (uint32_t)__builtin_amdgcn_readlane((int)mprefix, 0);   // matches in front of the next entry = its index into `chosen`
+            uint32_t p_pos = 0, p_byte = 0, p_rec = 0; uint64_t p_live = 0;  // the trip whose operands are in flight
+            auto hand_over = [&](uint32_t pos, uint32_t byte, uint32_t rec, uint64_t live_mask) {
+                if (p_live) work(p_pos, p_byte, p_rec, (bool)((p_live >> lane) & 1ull));
+                p_pos = pos; p_byte = byte; p_rec = rec; p_live = live_mask;
             };
-            for (uint32_t it = 0; it < trips; it++) {
-                const uint64_t sw = word_of(sym_l, it);                    // readlane outside divergent code
-                if (sw == 0) continue;                                     // wave-uniform
-                const uint64_t mw = word_of(mst_l, it);
-                const uint32_t mfirst = (uint32_t)__builtin_amdgcn_readlane((int)mprefix, it);
-                if ((sw >> lane) & 1ull) {
-                    const uint32_t is_m = (uint32_t)(mw >> lane) & 1u;
-                    queue[(tail + rank_in(sw)) & (kEncQueue - 1u)] = (seg + (it << 6) + lane) | (is_m ? 0x80000000u | (mfirst + rank_in(mw)) << 16 : 0u);
+            auto take = [&](uint32_t n) {                                  // fetch for n waiting entries, then work on the trip taken before
+                const uint32_t ent = queue[(head + lane) & (kCap - 1u)];            // (lanes >= n: stale entries, masked by `live`)
+                const bool live = lane < n;
+                const uint32_t pos = seg + (ent & 0xfffu);
+                const uint64_t mm = __builtin_amdgcn_ballot_w64(live && (ent >> 15));
+                const bool is_m = (mm >> lane) & 1ull;
+                const uint32_t byte = live ? (uint32_t)data[pos] : 0u;
+                const uint32_t rec = is_m ? chosen[m_run + rank_in(mm)] : 0u;       // dense: 4 bytes per match
+                m_run += (uint32_t)__popcll(mm);
+                head += n;
+                hand_over(pos, byte, rec, n >= 64u ? ~0ull : (1ull << n) - 1ull);
+            };
+            auto word_of = [&](uint64_t v, uint32_t it) -> uint64_t {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, it);          // the builtin returns int:
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), it);  // widen only after the cast
+                return (uint64_t)lo | ((uint64_t)hi << 32);
+            };
+            auto direct = [&](uint32_t w) {                                // a word that is nearly all symbol starts is a trip as it stands: lane = position
+                const uint64_t sw = word_of(sym_l, w), mw = word_of(mst_l, w);
+                const bool live = (sw >> lane) & 1ull, is_m = (mw >> lane) & 1ull;
+                const uint32_t pos = seg + (w << 6) + lane;
+                const uint32_t byte = live ? (uint32_t)data[pos] : 0u;
+                const uint32_t rec = is_m ? chosen[m_run + rank_in(mw)] : 0u;
+                m_run += (uint32_t)__popcll(mw);
+                if (sw) hand_over(pos, byte, rec, sw);
+            };
+            while (next < trips) {
+                const uint32_t src = next + (lane >> 2), qsh = (lane & 1u) << 4;
+                const int from = (int)((src & 63u) << 2);
+                const uint32_t s_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)sym_l), s_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(sym_l >> 32));
+                const uint32_t m_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)mst_l), m_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(mst_l >> 32));
+                uint32_t bits = src < trips ? (((lane & 2u) ? s_hi : s_lo) >> qsh) & 0xffffu : 0u;
+                const uint32_t mbits = (((lane & 2u) ? m_hi : m_lo) >> qsh) & 0xffffu;
+                const uint32_t c = (uint32_t)__popc(bits), incl = wave_scan_incl(c);
+                if ((uint32_t)__builtin_amdgcn_readlane((int)incl, 15) >= 192u) {       // the next four words hold >= 48 starts each (image-like data: literals)
+                    if (tail != head) take(tail - head);                   // (what waits goes first)
+                    for (uint32_t k = 0; k < 4u && next < trips; k++, next++) direct(next);
+                    continue;
                 }
-                tail += (uint32_t)__popcll(sw);
+                const uint32_t room = kCap - (tail - head);                // > 192
+                const uint64_t in = __builtin_amdgcn_ballot_w64(incl <= room);       // the counts ascend: lanes 0 .. nl - 1
+                const uint32_t nl = (~in ? (uint32_t)__builtin_ctzll(~in) : 64u) & ~3u;          // whole words only (>= 4: a word holds <= 64)
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, nl - 1u);
+                if (lane < nl) {
+                    uint32_t at = tail + incl - c;
+                    const uint32_t base = (src << 6) | ((lane & 3u) << 4);
+                    while (bits) {
+                        const uint32_t bpos = (uint32_t)__builtin_ctz(bits);
+                        queue[at & (kCap - 1u)] = (uint16_t)(base | bpos | ((mbits >> bpos) & 1u) << 15);
+                        at++; bits &= bits - 1u;
+                    }
+                }
+                tail += total; next += nl >> 2;
                 while (tail - head >= 64u) take(64u);
             }
             if (tail != head) take(tail - head);
-            if (p_n) work(p_ent, p_byte, p_rec, lane < p_n);
+            if (p_live) work(p_pos, p_byte, p_rec, (bool)((p_live >> lane) & 1ull));
         };
 
+        // the waves' Adler partials go to LDS here: whoever writes the stream's last words adds them up (no barrier of its own for the checksum)
+        for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
+        if (lane == 0) { s_adler_a[wave] = a_sum; s_adler_b[wave] = b_sum; }
         ZWZ_ESTAMP(2);                                        // Adler partials, stored blocks' bytes
         // One Huffman block: ONE pass.  A wave does not know where its segment's bits start before every wave in front of it has added
         // up its code lengths -- rounds 1-4 made a first pass over the symbols for that sum alone (28 % of the kernel: every byte and
-        // every chosen record fetched twice).  Here a wave packs its segment at a PRIVATE place first -- a slot of seven bits a position
-        // in the same staging buffer (a segment of text needs three) -- then, the wave totals known, reads its slot into registers, clears
+        // every chosen record fetched twice).  Here a wave packs its segment at a PRIVATE place first -- a slot of up to nine bits a position
+        // in the same staging buffer (enc_slot_bits; a segment of text needs three) -- then, the wave totals known, reads its slot into registers, clears
         // it, and ORs the words back shifted to where they belong.  A wave whose segment outgrows its slot sends the chunk through the two
         // passes below (never on the corpora).
         bool two_pass = !one_pass;
         if (one_pass) {
-            const uint32_t slot_bits = (wpw * 64u * 7u + 31u) & ~31u, slot0 = (s_blk[0].body_pos + 63u) & ~31u;
+            const uint32_t slot_bits = enc_slot_bits(wpw, s_blk[0].body_pos, s_blk[0].body_bits), slot0 = (s_blk[0].body_pos + 63u) & ~31u;
             const uint32_t q = slot0 + wave * slot_bits;                                       // a multiple of 32
             uint32_t running = 0;
             for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
@@ -1685,40 +1743,26 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             ZWZ_ESTAMP(3);
             __syncthreads();
             ZWZ_ESTAMP(4);
-            uint32_t before = 0; bool fits = true;
-            for (uint32_t i = 0; i < kEncodeThreads / 64u; i++) { const uint32_t m = s_wsum[i]; before += i < wave ? m : 0u; fits = fits && m <= slot_bits; }
-            fits = fits && slot0 + (kEncodeThreads / 64u) * slot_bits + 64u <= kOutWords * 32u;  // (the slots themselves fit the buffer)
+            // lane i < 16: wave i's bits; the scan gives every wave all sixteen starts
+            const uint32_t m_l = lane < kEncodeThreads / 64u ? s_wsum[lane] : 0u;
+            pre_l = wave_scan_incl(m_l) - m_l;                                                 // lane 16: all the symbols' bits
+            const bool fits = __builtin_amdgcn_ballot_w64(m_l > slot_bits) == 0 && slot0 + (kEncodeThreads / 64u) * slot_bits + 64u <= kOutWords * 32u;   // (.. and the slots themselves fit the buffer)
             if (fits) {
-                // The slots lie at or behind where their bits belong (slot0 >= body_pos, a wave's bits <= its slot), so they move in place, FOUR slots
-                // a turn by the whole workgroup (256 threads a slot, four words each): read and cleared, a barrier, ORed back at their destination
-                // -- words of these four slots (clear now) or of slots moved in earlier turns.  (First form: a wave moved its own slot, the waves
-                // in turn -- sixteen barriers with one wave working: the move cost as much as the pass it replaced.  Fourteen words a lane held
-                // across ONE barrier went to scratch under this kernel's 64 registers: 216 bytes a lane.)
-                if (tid < kEncodeThreads / 64u) { uint32_t pre = 0; for (uint32_t i = 0; i < tid; i++) pre += s_wsum[i]; s_msum[tid] = pre; }   // (s_msum: the match prefixes are in registers)
-                __syncthreads();
-                const uint32_t slot_words = slot_bits >> 5, u = tid & 255u;
-#pragma unroll 1
-                for (uint32_t turn = 0; turn < 4u; turn++) {
-                    const uint32_t sw = turn * 4u + (tid >> 8);                              // the slot this thread works on
-                    const uint32_t nw = (s_wsum[sw] + 31u) >> 5, base = (slot0 >> 5) + sw * slot_words;
-                    uint32_t w[4];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; w[k] = i < nw ? s_out[base + i] : 0u; }
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; if (i < nw) s_out[base + i] = 0u; }
-                    __syncthreads();
-                    const uint64_t dst = (uint64_t)s_blk[0].body_pos + s_msum[sw];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = u + 256u * k; if (w[k]) lds_or_bits(s_out, dst + 32ull * i, w[k], 32); }
-                    __syncthreads();
-                }
-                write_headers();
-            } else {
+                // The slots stay where they are: the stream is put together on its way OUT (below) -- a word of it is the header's bits (in front of
+                // the first slot, written above), at most a few slots' bits funnel-shifted to where the wave totals say they belong, the end-of-block
+                // code and the checksum.  No barrier from here to the end of the chunk.  (Two forms that MOVED the slots inside the buffer first -- a
+                // wave its own slot, the waves in turn; four slots a turn by the whole workgroup, read + cleared, a barrier, ORed back -- cost sixteen
+                // resp. nine barriers and 14 k LDS atomics a chunk: 7.32 and 7.12 ms on text against the two passes' 8.33.  And between barriers
+                // a workgroup is sixteen waves each running a short serial piece at an eighth of a SIMD: the prefix over the wave totals by
+                // seventeen lanes and the checksum's last step by one thread -- two barriers -- were 40 k cycles a chunk.)
+                if (lane <= kEncodeThreads / 64u) s_msum[lane] = pre_l;                         // every wave writes the same seventeen words and reads back its own: no barrier
+                in_slots = true;
+                        } else {
                 two_pass = true;                                                               // workgroup-uniform: s_wsum is everybody's
                 __syncthreads();
                 for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
                 __syncthreads();
-                write_headers();
+                write_headers(true);
             }
         }
       if (two_pass) {
@@ -1756,27 +1800,64 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
 
     ZWZ_ESTAMP(5);                                            // second pass: bits into the staging buffer
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
-    for (uint32_t d = 32; d >= 1; d >>= 1) { a_sum += __shfl_down(a_sum, d); b_sum += __shfl_down(b_sum, d); }
-    if (lane_id() == 0) { s_adler_a[tid >> 6] = a_sum; s_adler_b[tid >> 6] = b_sum; }
-    __syncthreads();
-    if (tid == 0) {
+    auto adler_be = [&]() -> uint32_t {
         unsigned long long a = 1, b = L;
         for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_adler_a[i]; b += s_adler_b[i]; }
-        const uint32_t ad = (uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull);
-        const uint32_t be = __builtin_bswap32(ad);
-        lds_or_bits(s_out, 8ull * (s_total_bytes - 4), be, 32);
-        out_len[chunk] = s_total_bytes < kChunk ? s_total_bytes : kChunk;
-    }
-    __syncthreads();
+        return __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
+    };
     const uint32_t n_out = s_total_bytes < kChunk ? s_total_bytes : kChunk;
     uint32_t* gout = reinterpret_cast<uint32_t*>(out + (size_t)chunk * out_stride);
+    if (tid == 0) out_len[chunk] = n_out;
+    if (!in_slots) {
+        __syncthreads();
+        if (tid == 0) lds_or_bits(s_out, 8ull * (s_total_bytes - 4), adler_be(), 32);
+        __syncthreads();
+    }
     ZWZ_ESTAMP(6);                                            // waiting for the other waves, the checksum
-    for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
+    if (!in_slots) {
+        for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
+    } else {
+        // word j of the stream = bits [32 j, 32 j + 32): header words as they lie; of the symbols, slot w holds bits [body + msum[w], + wsum[w]) from its own first bit on
+        const uint32_t body = s_blk[0].body_pos, slot_bits = enc_slot_bits(wpw, body, s_blk[0].body_bits), slot0 = (body + 63u) & ~31u;
+        const uint32_t sym_end = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, kEncodeThreads / 64u);
+        const uint32_t eob_code = s_blk[0].eob_code, ad_pos = 8u * (s_total_bytes - 4u);
+        uint32_t d_of[kEncodeThreads / 64u];                  // (scalar registers: the same for every lane)
+#pragma unroll
+        for (uint32_t i = 0; i < kEncodeThreads / 64u; i++) d_of[i] = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, i);
+        auto piece = [](uint32_t pos, uint32_t val, uint32_t bit) -> uint32_t {       // of val laid down at bit `pos`, what falls into [bit, bit + 32)
+            const int d = (int)pos - (int)bit;
+            return d >= 32 || d <= -32 ? 0u : d >= 0 ? val << d : val >> (-d);
+        };
+        for (uint32_t j = tid; j < ((n_out + 3) >> 2); j += kEncodeThreads) {
+            const uint32_t bit = j << 5;
+            uint32_t v = j < (slot0 >> 5) ? s_out[j] : 0u;
+            v |= piece(sym_end, eob_code, bit);
+            if (bit + 32u > ad_pos) v |= piece(ad_pos, adler_be(), bit);      // (the stream's last one or two words)
+            if (bit + 32u > body && bit < sym_end) {
+                uint32_t w = 0;                               // the slot bit `bit` falls into (the first one for the header's last word)
+#pragma unroll
+                for (uint32_t i = 1; i < kEncodeThreads / 64u; i++) w += d_of[i] <= bit ? 1u : 0u;
+                for (; w < kEncodeThreads / 64u; w++) {
+                    const uint32_t d = body + s_msum[w];
+                    if (d >= bit + 32u) break;
+                    const int sft = (int)bit - (int)d, len = (int)s_wsum[w];
+                    const int lo = sft < 0 ? -sft : 0, hi = len - sft < 32 ? len - sft : 32;
+                    if (hi > lo) {
+                        const uint32_t at = (uint32_t)((int)(slot0 + w * slot_bits) + sft), aw = at >> 5;
+                        const uint32_t x = __builtin_amdgcn_alignbit(s_out[aw + 1u], s_out[aw], at & 31u);
+                        const uint32_t mask = (hi >= 32 ? 0xffffffffu : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+                        v |= x & mask;
+                    }
+                }
+            }
+            gout[j] = v;
+        }
+    }
     __syncthreads();                                          // everyone has read s_item, s_total_bytes and s_out
     ZWZ_ESTAMP(7);                                            // the stream out
   }
 #if ZWZ_ENC_EXP & 16
-    if (tid == 0) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&g_enc_times[ph], (unsigned long long)(eacc_[ph] >> 8));
+    if (tid == ((ZWZ_ENC_EXP & 32) ? 960u : 0u)) for (uint32_t ph = 0; ph < 8; ph++) atomicAdd(&g_enc_times[ph], (unsigned long long)(eacc_[ph] >> 8));   // (& 32: as the last wave sees it)
 #endif
 }
 

@@ -98,11 +98,11 @@ def test_plan_stage_skewed_histograms(zwz, oracle, mode):
 
 
 def test_encode_single_block_chunks_whose_bits_outgrow_the_private_slots(codec, oracle):
-    """encode packs a chunk of ONE Huffman block in a single pass: every wave at a private slot of seven bits a position, then the slots are
-    shifted into place (csrc/zwz_kernels.hip, round 5).  Data that a dynamic block codes at MORE than seven bits a symbol -- 150 to 250
-    equiprobable byte values, few enough bytes for one block -- outgrows the slots and must come out of the two-pass fallback the same;
-    so must chunks right at the edge (around 128 symbols: 7 bits), short chunks whose sixteen waves hold a word each, and chunks whose
-    segments are lopsided (text in front, dense bytes behind)."""
+    """encode packs a chunk of ONE Huffman block in a single pass: every wave at a private slot, the stream put together from the slots on its
+    way out (csrc/zwz_kernels.hip, round 5).  A wave whose bits outgrow its slot sends the chunk through the two-pass fallback, which must
+    give the same bytes: dense data (150 to 250 equiprobable byte values, few enough bytes for one block: 7+ bits a symbol), chunks at the
+    edge of nine bits a position, short chunks whose sixteen waves hold a word each, and lopsided chunks (text in front, dense bytes behind;
+    one dense stretch in a chunk of zeros)."""
     rs = np.random.RandomState(4711)
     chunks = []
     for nsym in (100, 120, 128, 136, 150, 180, 220, 250, 256):
@@ -113,6 +113,12 @@ def test_encode_single_block_chunks_whose_bits_outgrow_the_private_slots(codec, 
         dense = rs.choice(256, 200, replace=False)[rs.randint(0, 200, n // 2)].astype(np.uint8).tobytes()
         chunks.append(corpus.text_like(31337 + n, n // 2) + dense)
         chunks.append(dense + corpus.text_like(31338 + n, n // 2))
+    # a slot is twice a wave's SHARE of the block's bits (enc_slot_bits): one dense stretch in an otherwise empty chunk outgrows it
+    for n0, nd in ((12000, 1500), (30000, 3000), (60000, 4000), (3000, 400)):
+        dense = rs.choice(256, 200, replace=False)[rs.randint(0, 200, nd)].astype(np.uint8).tobytes()
+        chunks.append(b"\0" * n0 + dense)
+        chunks.append(dense + b"\0" * n0)
+        chunks.append(b"\0" * (n0 // 2) + dense + b"ab" * (n0 // 4))
     got = codec.deflate_chunks(chunks)
     for i, (c, g) in enumerate(zip(chunks, got)):
         assert g == oracle.payload(c), (i, len(c))
