@@ -201,7 +201,10 @@ __global__ __launch_bounds__(kSortThreads) void lz_sort_kernel(const uint8_t* __
         // (Round 5, measured and dropped: ALL FOUR waves ranking, each the positions whose bucket lies in its quarter of the table -- buckets do not
         // care about each other, so it is exact (all oracle tests passed) -- on the idea that the step is latency over what is in flight: links stage
         // 7.1 -> 10.4 ms on text.  Every wave then loads all the hashes, and the per-lane guards around add and store are the exec-mask bookkeeping
-        // the unguarded trips below got rid of.)
+        // the unguarded trips below got rid of.  Also measured and dropped: NO histogram -- the ranking's returning add counts from zero and hands a
+        // position its rank inside its bucket, the scan comes afterwards, and a last pass of plain LDS reads adds the bucket's start to every rank
+        // (on the idea that the LDS's atomics bound the kernel and the histogram is a third of them): exact, 7.1 -> 8.5 ms.  The histogram's adds
+        // overlap the other workgroup's ranking; the last pass's two global round trips a position vector do not.)
         if (wave == 0) {
             // Whole trips of eight steps run without a single test (every lane has a position: guarded per lane, the loop was
             // mostly exec-mask bookkeeping); the next trip's hashes are on their way while this one ranks.
