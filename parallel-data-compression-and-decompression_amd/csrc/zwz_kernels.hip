@@ -1069,6 +1069,11 @@ __global__ __launch_bounds__(kParseThreads) void lz_parse_kernel(const uint32_t*
             if ((nonlit >> e0) == 0) {
                 marks = validm & ~((1ull << e0) - 1ull);                 // only literals from the entry on
             } else {
+                // (Round 5, measured and dropped: the orbit by scalar code that hops only at MATCHES -- from where it stands the walk takes every
+                // position up to the next lane that is not a literal (find-first-bit on the ballot, the run marked with two shifts) and goes on
+                // where that lane's match ends (v_readlane): five jumps a block on text, ~14 scalar instructions each, nothing for the vector
+                // unit.  Exact (all oracle tests); text 13.7 -> 17.8 ms, 370 000 image-like files 23.0 -> 31.7 ms: a jump is a chain of dependent
+                // scalar issues, each a turn among the SIMD's waves, and the doubling's rounds are fewer turns than the jumps'.)
                 // (Round 4, measured and dropped again: the orbit by a scalar hop -- v_readlane + a few scalar instructions a symbol, as in
                 // inflate -- for the chunks lz_dense_list marks chain-heavy: text 15.3 -> 16.9 ms, 7 KB image-like files 6.7 -> 11.4 ms per
                 // 100 000 chunks: a block of mostly literals is sixty hops, and six rounds of doubling cost less than fifteen hops.)
@@ -1881,7 +1886,7 @@ __device__ unsigned long long g_inf_times[8];
 #ifndef ZWZ_INF_WAVES
 #define ZWZ_INF_WAVES 5
 #endif
-constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;
+constexpr uint32_t kInflateWavesPerSimd = ZWZ_INF_WAVES;   // (round 5: six, with the owner map cut to 512 bytes and sharing the code lengths' place -- 6.6 KB a wave -- 22.42 -> 22.27 ms on text: noise, and 8 bytes of scratch)
 #ifndef ZWZ_WIN_SLOTS
 #define ZWZ_WIN_SLOTS 4
 #endif
@@ -2218,7 +2223,10 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
                 for (uint32_t r = 0; r < kWinSlots; r++) {
                     uint64_t mk = 0;
                     const uint32_t lim = wb + 64u * (r + 1u);
-                    auto hop = [&] { const uint32_t l = at - wb - 64u * r; mk |= 1ull << l; at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)l); };
+                    // (the mark is ONE scalar instruction -- s_bitset1_b64 takes the bit number from the low six bits of `at`, as v_readlane does its lane:
+                    // offsets are counted from a multiple of 64 -- where `mk |= 1ull << (at - wb - 64 r)` compiled to subtract, shift, or: a hop is a chain of
+                    // dependent scalar issues, each a turn among the SIMD's five waves, and six of them became four)
+                    auto hop = [&] { asm volatile("s_bitset1_b64 %0, %1" : "+s"(mk) : "s"(at)); at = (uint32_t)__builtin_amdgcn_readlane((int)jr[r], (int)at); };
                     while (at < lim) {                                        // (at >= wb + 64 r: offsets only grow)
                         hop();                                                // four hops a trip by hand (the optimizer does not unroll around a
                         if (at >= lim) break;                                 // v_readlane): three of four loop branches fall through instead of
@@ -2350,6 +2358,9 @@ __global__ __launch_bounds__(kInflateThreads, kInflateWavesPerSimd) void inflate
                     if (__ballot(live && off >= d)) from = off < d ? from : op - d + off % (d | (uint32_t)!live);
                     return from;
                 };
+                // (Round 5, measured and dropped: the sources of four trips worked out first, their loads sent out together, then the stores -- on the
+                // idea that a trip's load is an L2 round trip the wave stands through, three a round on text: inflate 22.93 -> 22.87 ms, the copy's share
+                // of a wave's time 30 -> 32 %.  With twenty waves a CU the round trips are covered by the other waves; the kernel is bound by vector issue.)
                 bool need_fence = false;
                 for (uint32_t j0 = 0; j0 < bbytes; j0 += 64) {
                     const uint32_t pos = bstart + j0 + lane;
