@@ -420,6 +420,11 @@ __global__ __launch_bounds__(kBandThreads, ZWZ_BAND_WAVES) void lz_match_band_ke
             // the entries that fail the check.  On the text corpus nearly every wave holds such an entry (a rare trigram's candidates lie
             // further back than MAX_DIST for every position in the chunk's second half), so the search ran anyway, behind the scan and a
             // barrier: this phase 3.93 M -> 5.45 M cycles >> 8 per 10 000 chunks, 6.56 M with the fallback's searches advancing together.)
+            // (Round 5, measured and dropped: a thread takes six CONSECUTIVE entries, searches the first and derives each next count from the one before
+            // -- an entry behind one of its own bucket has that one as a candidate plus those of its candidates still in reach, so its count is
+            // the previous + 1 less what fell out at the far end: one probe there and one more per entry that did, ~23 probes a thread where the
+            // searches make 48.  Exact (all oracle tests); this phase 3.67 M -> 4.77 M, text match stage 68.5 -> 70.7 ms: the 23 probes hang on one
+            // another, the six searches run side by side -- the phase is the LDS round trip times the length of the chain, not its probes.)
             // ---- count (thread <-> entries kBand + tid + 1024 j: the searches of a thread's entries advance together)
             {
                 constexpr uint32_t kOwnPer = (kBandTile + kBandThreads - 1) / kBandThreads;

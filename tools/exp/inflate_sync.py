@@ -105,3 +105,32 @@ if __name__ == "__main__":
     for S in (128, 256):
         study("text-like (configs[2])", text, S)
         study("image-like small files (configs[3])", img, S)
+
+
+def long_codes(name, chunks):
+    """share of TRUE symbols whose literal/length code is longer than the kernel's 10-bit fast table (or whose distance code is longer than 8),
+    and the share of ARBITRARY bit offsets at which a decode runs into one (or into no code at all)"""
+    n = long_true = n_any = long_any = 0
+    for c in chunks:
+        fb = first_block(zlib.compress(c, 6))
+        if fb is None: continue
+        b, p0, lt, dt, starts, end = fb
+        def is_long(pos):
+            for l in range(1, 16):
+                s = lt.get((l, b.get(pos, l)))
+                if s is not None:
+                    if l > 10: return True
+                    if s <= 256: return False
+                    p = pos + l + LEXT[s - 257]
+                    for dl in range(1, 16):
+                        d = dt.get((dl, b.get(p, dl)))
+                        if d is not None: return dl > 8
+                    return True
+            return True
+        for pos in starts: n += 1; long_true += is_long(pos)
+        for pos in range(p0, min(end, p0 + 40000), 7): n_any += 1; long_any += is_long(pos)
+    print("== %s: true symbols with a code beyond the fast tables: %.2f %% (one in %.0f); arbitrary offsets: %.2f %%" % (name, 100.0 * long_true / n, n / max(1, long_true), 100.0 * long_any / n_any))
+
+if __name__ == "__main__":
+    long_codes("text-like", text)
+    long_codes("image-like small files", img)
