@@ -32,14 +32,14 @@
 namespace zwz {
 
 // ------------------------------------------------------------------------------------------------
-// lz_dense_list: a wave per chunk hashes the chunk's first kDenseSample trigrams into a 32 Ki-bit set (LDS) and counts the ones
-// whose bucket was taken already.  Chain-heavy chunks get kDenseMark in link_stat[], the others 0 (for lz_links to count in);
-// lz_lists turns the marks into the two lists.
+// lz_dense_list: a wave per chunk hashes the chunk's first kDenseSample trigrams into two 32 Ki-bit sets (LDS) -- bucket taken, bucket
+// taken twice -- and counts the ones that are at least the second resp. the third of their bucket (zwz_kernels.h: sample_is_dense).
+// Chain-heavy chunks get kDenseMark in link_stat[], the others 0 (for lz_links to count in); lz_lists turns the marks into the two lists.
 constexpr uint32_t kDenseThreads = 256;
 __global__ __launch_bounds__(kDenseThreads) void lz_dense_list_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                       const uint32_t* __restrict__ in_len, uint32_t n, uint32_t* __restrict__ link_stat,
                                                                       uint32_t force /* 2: every chunk is chain-heavy */) {
-    __shared__ uint32_t s_set[kDenseThreads / 64][1024];
+    __shared__ uint32_t s_set[kDenseThreads / 64][2048];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     uint32_t* set = s_set[wave];
     // persistent: a wave takes chunks wave-id, + all waves, ... (a workgroup per four chunks spent more time being dispatched than working)
@@ -47,11 +47,11 @@ __global__ __launch_bounds__(kDenseThreads) void lz_dense_list_kernel(const uint
         const uint32_t L = in_len[c];
         bool dense = force == 2u && L != 0u;
         if (!dense && L >= kMinMatch) {
-            for (uint32_t i = lane; i < 1024u; i += 64u) set[i] = 0;
+            for (uint32_t i = lane; i < 2048u; i += 64u) set[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint32_t* d32 = reinterpret_cast<const uint32_t*>(in + in_off[c]);       // 16-byte aligned; readable to L rounded up to 16
             const uint32_t sampled = min(L - (kMinMatch - 1u), kDenseSample), nd = ((L + 15u) & ~15u) >> 2;
-            uint32_t repeats = 0;
+            uint32_t repeats = 0, thirds = 0;
             static_assert(kDenseSample == 2048, "eight trips of 256 positions, their loads asked for together");
             uint32_t w0[8], w1[8];                                                      // four positions a lane a trip: a dword and its successor
 #pragma unroll
@@ -67,12 +67,15 @@ __global__ __launch_bounds__(kDenseThreads) void lz_dense_list_kernel(const uint
                     const uint32_t x = j ? __builtin_amdgcn_alignbyte(w1[t], w0[t], j) : w0[t];
                     const uint32_t h = hash3(x & 0xffu, (x >> 8) & 0xffu, (x >> 16) & 0xffu);
                     const bool live = 256u * t + 4u * lane + j < sampled;
-                    uint32_t old = 0;
+                    uint32_t old = 0, old2 = 0;
                     if (live) old = atomicOr(&set[h >> 5], 1u << (h & 31u));            // (same-word lanes are served one after the other: each sees the earlier ones' bits)
-                    repeats += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && ((old >> (h & 31u)) & 1u)));
+                    const bool again = live && ((old >> (h & 31u)) & 1u);
+                    if (again) old2 = atomicOr(&set[1024u + (h >> 5)], 1u << (h & 31u));
+                    repeats += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(again));
+                    thirds += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(again && ((old2 >> (h & 31u)) & 1u)));
                 }
             }
-            dense = sample_is_dense(repeats, sampled);
+            dense = sample_is_dense(repeats, thirds, sampled, L);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         if (lane == 0) link_stat[c] = dense ? kDenseMark : 0u;

@@ -8,6 +8,7 @@ corpus.random_bytes(seed, n) (checked by tests/test_workloads.py on the CPU).
 A batch is the reference's chunking of n_files files (compression.cpp:52-64): 65 535-byte reads until a short one, each
 chunk in its own 65 536-byte slot.
 """
+import os
 import numpy as np
 
 import corpus
@@ -107,7 +108,8 @@ def small_file_sizes(n_files, seed=4):
     u = (corpus.splitmix64(seed, 2 * n_files) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
     g = np.sqrt(-2.0 * np.log(np.maximum(u[0::2], 1e-300))) * np.cos(2.0 * np.pi * u[1::2])      # Box-Muller
     sigma = 0.9
-    sizes = np.exp(np.log(6800.0) - sigma * sigma / 2.0 + sigma * g)
+    mean = float(os.environ.get("ZWZ_SMALL_MEAN", "6800"))      # (tools/exp/dense_crossover.sh varies it; the workload is the default)
+    sizes = np.exp(np.log(mean) - sigma * sigma / 2.0 + sigma * g)
     return np.clip(sizes, 16, 400_000).astype(np.int64)
 
 
