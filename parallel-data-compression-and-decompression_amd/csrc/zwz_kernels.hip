@@ -1466,6 +1466,9 @@ __device__ unsigned long long g_enc_times[8];
 #else
 #define ZWZ_ESTAMP(ph) do { } while (0)
 #endif
+// (Round 5, measured and dropped: the kernel as a template -- a one-pass launch for the chunks of one Huffman block, a two-pass launch for the others and
+// for the overflows, handed over through a second list -- so that each has half the code: scratch 76 -> 20 bytes a lane in the one-pass kernel, text
+// 5.66 -> 6.12 ms.  What the scratch holds is read at the head of phases, not in the trips; what the split changed was the allocation inside them.)
 __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
