@@ -26,6 +26,24 @@ constexpr uint32_t kBand = kMaxChain;            // candidates a position may lo
 constexpr uint32_t kBandNoLink = 0xffffu;
 constexpr uint32_t kBandHaloWord = 0xffff0000u;  // "no entry": bucket 0xffff (no hash is), position 0
 
+// lz_dense_list's sample: the chunk's first kDenseSample trigrams.
+constexpr uint32_t kDenseSample = 2048;
+// Round 5: the rule weighs what the search would have to walk, not how often buckets repeat.  The sample counts the positions that are at least the SECOND
+// in their bucket (repeats) and those that are at least the THIRD (thirds).  With the tail taken as geometric the mean number of earlier same-bucket
+// positions in the sample would be repeats + thirds / (1 - thirds / repeats), over `sampled`; text's buckets are heavier-tailed than that (its commonest
+// trigrams: 12.6 candidates a position in an 8 KB chunk where the geometric tail says 5.9), so the tail term counts three times; over the whole chunk
+// the mean is L / sampled times the sample's.  Chain-heavy = 3.6 or more: where the two paths cross on image-like files (mean 16 KB: sort + band 26.7 ms,
+// chain walk 28.1 per 1.3 GB; mean 6.8 KB -- BASELINE configs[3] --: 33.1 against 22.5), with text-like chunks on the band from 4 KB up (44 against
+// 89 ms) -- tools/exp/dense_crossover.sh, tools/exp/dense_sample.py; tests/test_emu.py pins the choices.  (Rounds 3 - 4: repeats >= sampled / 5, whatever
+// the length: the 7 KB image-like files, 0.24 repeats and 1.2 candidates a position, went to the band.)  Either path gives the same records: the
+// choice is speed only.
+ZWZ_HD bool sample_is_dense(uint32_t repeats, uint32_t thirds, uint32_t sampled, uint32_t L) {
+    if (repeats == 0u || sampled == 0u) return false;
+    if (thirds >= repeats) return true;                                       // every repeat is a third one: a run
+    const float walk = ((float)repeats + 3.0f * (float)thirds * (float)repeats / (float)(repeats - thirds)) * (float)L / ((float)sampled * (float)sampled);
+    return walk >= 3.6f;
+}
+
 ZWZ_HD uint32_t band_word(uint32_t h, uint32_t p) { return h << 16 | p; }
 ZWZ_HD uint32_t band_pos(uint32_t w) { return w & 0xffffu; }
 ZWZ_HD uint32_t band_hash(uint32_t w) { return w >> 16; }

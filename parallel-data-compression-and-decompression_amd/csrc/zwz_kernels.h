@@ -5,6 +5,7 @@
 
 #include "huff_core.h"
 #include "zwz_common.h"
+#include "lz_band.h"
 
 namespace zwz {
 
@@ -145,20 +146,7 @@ __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { re
 // With the band kernels: lz_dense_list looks at a chunk's first kDenseSample positions and calls it chain-heavy -- sort + band --
 // by sample_is_dense below (incompressible bytes: one position in thirty falls into a bucket taken already; the text corpus: two in
 // five); its mark in link_stat[] tells lz_match which chunks are not its own.
-constexpr uint32_t kDenseSample = 2048, kDenseMark = 0xffffffffu;
-// Round 5: the rule weighs what the search would have to walk, not how often buckets repeat.  The sample counts the positions that are at least the SECOND
-// in their bucket (repeats) and those that are at least the THIRD (thirds); with the tail taken as geometric the mean number of earlier same-bucket
-// positions in the sample is repeats + thirds / (1 - thirds / repeats), all over `sampled`, and over the whole chunk L / sampled times that.  Chain-heavy
-// = 2.5 candidates a position or more: where the two paths cross on image-like files (mean 16 KB: sort + band 26.7 ms, chain walk 28.1 per 1.3 GB;
-// mean 6.8 KB -- BASELINE configs[3] --: 33.1 against 22.5), with text-like chunks on the band from 4 KB up (44 against 89 ms) -- tools/exp/dense_crossover.sh,
-// tools/exp/dense_sample.py.  (Rounds 3 - 4: repeats >= sampled / 5, whatever the length: the 7 KB image-like files, 0.24 repeats and 1.2 candidates a
-// position, went to the band.)  Either path gives the same records: the choice is speed only.
-__host__ __device__ inline bool sample_is_dense(uint32_t repeats, uint32_t thirds, uint32_t sampled, uint32_t L) {
-    if (repeats == 0u || sampled == 0u) return false;
-    if (thirds >= repeats) return true;                                       // every repeat is a third one: a run
-    const float walk = ((float)repeats + (float)thirds * (float)repeats / (float)(repeats - thirds)) * (float)L / ((float)sampled * (float)sampled);
-    return walk >= 2.5f;
-}
+constexpr uint32_t kDenseMark = 0xffffffffu;   // (kDenseSample and sample_is_dense: lz_band.h, portable -- tests/emu pins the rule)
 constexpr size_t kWorkspaceBytesPerChunk =
     (size_t)kLinkStride * 2 + (size_t)kEntryStride * 8 + 3 * (size_t)kMaskWords * 8 + (size_t)kTile * 2 + 4 + sizeof(ChunkInfo) + (size_t)kSortedStride * 4 + 8 +
     kMaxBlocks * (sizeof(BlockInfo) + sizeof(BlockOut));

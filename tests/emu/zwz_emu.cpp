@@ -694,3 +694,19 @@ extern "C" uint32_t emu_lazy_check(const uint8_t* in, uint32_t L, uint32_t seg, 
     }
     return 0;
 }
+
+// ---- lz_dense_list's rule (lz_band.h: sample_is_dense) on a chunk: the sample counted as the kernel counts it
+extern "C" int emu_chunk_is_dense(const uint8_t* in, uint32_t L) {
+    using namespace zwz;
+    if (L < kMinMatch) return 0;
+    const uint32_t sampled = std::min(L - (kMinMatch - 1u), kDenseSample);
+    std::vector<uint8_t> seen(32768, 0);
+    uint32_t repeats = 0, thirds = 0;
+    for (uint32_t p = 0; p < sampled; p++) {
+        const uint32_t h = hash3(in[p], in[p + 1], in[p + 2]);
+        if (seen[h] >= 1) repeats++;
+        if (seen[h] >= 2) thirds++;
+        if (seen[h] < 2) seen[h]++;
+    }
+    return sample_is_dense(repeats, thirds, sampled, L) ? 1 : 0;
+}

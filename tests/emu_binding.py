@@ -28,6 +28,8 @@ def load():
     lib.emu_overflow_hits.restype = ctypes.c_uint64
     lib.emu_packed_window_check.restype = ctypes.c_uint32
     lib.emu_packed_window_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.emu_chunk_is_dense.restype = ctypes.c_int
+    lib.emu_chunk_is_dense.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
     lib.emu_lazy_check.restype = ctypes.c_uint32
     lib.emu_lazy_check.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     lib.emu_parse_blocks_check.restype = ctypes.c_int

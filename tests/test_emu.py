@@ -225,3 +225,23 @@ def test_packed_window_decode_agrees_with_the_classic_decoder(emu):
                     assert emu.emu_packed_window_check(v, len(v), ctypes.byref(a), ctypes.byref(c)) == 0, (kind, n, level, len(v))
                     total += a.value; slow += c.value
     assert total > 200000 and 0 < slow < total // 20
+
+
+def test_which_chunks_go_to_sort_and_band(emu):
+    """lz_dense_list's rule (csrc/lz_band.h: sample_is_dense) pinned on the corpora it was measured on (tools/exp/dense_crossover.sh, DESIGN.md section 4
+    round 5): text-like chunks from 4 KB up and full image-like chunks are chain-heavy (sort + band is 1.4 - 3.5x faster there), incompressible chunks
+    and the 7 KB image-like files of BASELINE configs[3] are not (the chain walk is 1.5x faster).  Either path gives the same records -- the GPU tests
+    force each -- so this is about speed only, and a change of the rule should be a decision, not an accident."""
+    import workloads
+    def dense(data):
+        return emu.emu_chunk_is_dense(data, len(data)) == 1
+    for n in (4096, 8192, 16384, 32768, 65535):
+        votes = [dense(corpus.text_like(900 + i, n)) for i in range(8)]
+        assert all(votes), (n, votes)
+    assert all(dense(corpus.gradient(77 + i, 65535)) for i in range(4))
+    assert not any(dense(corpus.random_bytes(5 + i, 65535)) for i in range(4))
+    sizes = workloads.small_file_sizes(300)
+    small = [workloads.small_file_bytes(i, sizes[i]) for i in range(300) if 2000 <= sizes[i] <= 9000]
+    assert len(small) > 100 and sum(dense(c) for c in small) == 0
+    big = [workloads.small_file_bytes(1000 + i, 48000) for i in range(6)]           # the same generator at 48 KB: the band's side of the crossing
+    assert all(dense(c) for c in big)
