@@ -56,6 +56,14 @@ constexpr uint32_t kBlockifyThreads = 256;
 constexpr uint32_t kEncodeThreads = 1024;                       // == kMaskWords
 constexpr uint32_t kOutWords = 16384;                           // 65536-byte staging, first 65535 kept
 constexpr uint32_t kEncQueue = 128;                               // entries of a wave's queue of symbol starts (a power of two >= 127)
+#ifndef ZWZ_SMALL_ENC_BYTES
+#define ZWZ_SMALL_ENC_BYTES 12288
+#define ZWZ_SMALL_ENC_OUT_WORDS 4096
+#define ZWZ_SMALL_ENC_WGS 6
+#endif
+constexpr uint32_t kSmallEncBytes = ZWZ_SMALL_ENC_BYTES, kSmallEncThreads = 256, kSmallEncOutWords = ZWZ_SMALL_ENC_OUT_WORDS, kSmallEncWgs = ZWZ_SMALL_ENC_WGS;   // encode's small form: chunks of one block and <= 12 KB, 16 KB of staging, four waves
+constexpr uint32_t kSmallEncLdsBytes = kSmallEncOutWords * 4 + (kSmallEncThreads / 64) * 128 * 4 + 5 * (288 * 2 + 32 * 2 + 288 + 32);
+static_assert(kEncQueue == 128 && kMaxBlocks == 5, "kSmallEncLdsBytes is written out with these");
 constexpr uint32_t kEncodeLdsBytes = kOutWords * 4 + (kEncodeThreads / 64) * kEncQueue * 4 + kMaxBlocks * (288 * 2 + 32 * 2 + 288 + 32);   // 78 528 bytes: two workgroups per CU (with __launch_bounds__(1024, 8): 64 registers)
 #ifndef ZWZ_INFLATE_THREADS
 #define ZWZ_INFLATE_THREADS 64
@@ -140,7 +148,7 @@ uint32_t exp_flags_kernels();   // ZWZ_MATCH_EXP | ZWZ_PARSE_EXP << 8 | ZWZ_ENC_
 uint32_t exp_flags_band();      // ZWZ_BAND_EXP
 
 constexpr size_t kTicketBytes = 256;
-enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7, kTicketLazyNext = 8 };   // indices into DeflateArgs::tickets
+enum : uint32_t { kTicketHuffCount = 0, kTicketHuffNext = 1, kTicketDenseCount = 2, kTicketSortNext = 3, kTicketBandNext = 4, kTicketPlaceNext = 5, kTicketSparseCount = 6, kTicketOpenCount = 7, kTicketLazyNext = 8, kTicketSmallCount = 9, kTicketSmallNext = 10 };   // indices into DeflateArgs::tickets
 // lz_match on its own (ZWZ_MATCH=walk): a chunk four of whose five positions have a chain predecessor (lz_links' count) takes the sorted walk.
 __host__ __device__ inline bool chunk_is_dense(uint32_t linked, uint32_t L) { return linked * 5u >= L * 4u; }
 // With the band kernels: lz_dense_list looks at a chunk's first kDenseSample positions and calls it chain-heavy -- sort + band --

@@ -1284,25 +1284,27 @@ __global__ __launch_bounds__(kBlockifyThreads) void blockify_kernel(const uint8_
 // encode: bit-pack one chunk's zlib stream into LDS, then stream the first <= 65535 bytes out.
 struct EncBlock { uint32_t type, hdr_pos, body_pos, body_bits, start, end, first_sym, eob_len, eob_code, sym_bits_before, data_byte; };
 
+template <uint32_t kCapWords = kOutWords>
 static __device__ __forceinline__ void lds_or_bits(uint32_t* out, uint64_t bitpos, uint64_t v, uint32_t n) {
     // OR n (<= 48) bits of v at absolute bit position; anything at or past word kOutWords is dropped
     if (n == 0) return;
     const uint32_t w = (uint32_t)(bitpos >> 5), o = (uint32_t)(bitpos & 31u);
     const uint64_t lo = v << o;
     const uint32_t hi = o ? (uint32_t)(v >> (64u - o)) : 0u;
-    if (w < kOutWords && (uint32_t)lo) atomicOr(&out[w], (uint32_t)lo);
-    if (w + 1 < kOutWords && (uint32_t)(lo >> 32)) atomicOr(&out[w + 1], (uint32_t)(lo >> 32));
-    if (w + 2 < kOutWords && hi) atomicOr(&out[w + 2], hi);
+    if (w < kCapWords && (uint32_t)lo) atomicOr(&out[w], (uint32_t)lo);
+    if (w + 1 < kCapWords && (uint32_t)(lo >> 32)) atomicOr(&out[w + 1], (uint32_t)(lo >> 32));
+    if (w + 2 < kCapWords && hi) atomicOr(&out[w + 2], hi);
 }
 
 // encode's private slots (one Huffman block, one pass): a wave packs its wpw words of positions at slot0 + wave * slot_bits first.  Twice a
 // wave's share of the block's bits (plan knows them), at most nine bits a position, or what the staging buffer has when that is less (a full chunk: 7.98 -- a Huffman chunk is smaller than its bytes as a whole, a
 // wave's segment need not be: then the chunk takes the two passes).  (Seven bits a position, the first form, sent most image-like chunks --
 // literals at 7+ bits -- through the attempt AND the two passes: configs[3]-shaped files 22.2 -> 33.7 ms.)
+template <uint32_t kWaves, uint32_t kCapWords>
 static __device__ __forceinline__ uint32_t enc_slot_bits(uint32_t wpw, uint32_t body_pos, uint32_t body_bits) {
-    const uint32_t slot0 = (body_pos + 63u) & ~31u, nine = wpw * 64u * 9u, twice = 2u * (body_bits / (kEncodeThreads / 64u)) + 1024u;
+    const uint32_t slot0 = (body_pos + 63u) & ~31u, nine = wpw * 64u * 9u, twice = 2u * (body_bits / kWaves) + 1024u;
     const uint32_t want = nine < twice ? nine : twice;                      // (the buffer is zeroed as far as the slots reach: no wider than need be)
-    const uint32_t have = kOutWords * 32u > slot0 + 64u ? (kOutWords * 32u - 64u - slot0) / (kEncodeThreads / 64u) : 0u;
+    const uint32_t have = kCapWords * 32u > slot0 + 64u ? (kCapWords * 32u - 64u - slot0) / kWaves : 0u;
     return (want < have ? want : have) & ~31u;
 }
 
@@ -1438,7 +1440,7 @@ __global__ __launch_bounds__(kEncStoredThreads) void encode_stored_kernel(const 
                                                                           const uint32_t* __restrict__ in_len, const ChunkInfo* __restrict__ info,
                                                                           const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
                                                                           uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
-                                                                          uint32_t* __restrict__ huff_list, uint32_t* __restrict__ tickets) {
+                                                                          uint32_t* __restrict__ huff_list, uint32_t* __restrict__ small_list, uint32_t* __restrict__ tickets) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t L = in_len[chunk], n_blocks = info[chunk].n_blocks;
     const BlockInfo* bi = blocks + (size_t)chunk * kMaxBlocks;
@@ -1448,7 +1450,10 @@ __global__ __launch_bounds__(kEncStoredThreads) void encode_stored_kernel(const 
     const uint32_t my_type = bo[lb].type, my_start = bi[lb].start, my_end = bi[lb].end;
     const bool all_stored = n_blocks > 0 && __builtin_amdgcn_ballot_w64(lane_id() < n_blocks && my_type != kStored) == 0;   // workgroup-uniform
     if (!all_stored) {
-        if (threadIdx.x == 0) huff_list[atomicAdd(&tickets[kTicketHuffCount], 1u)] = chunk;
+        if (threadIdx.x == 0) {
+            if (n_blocks == 1u && L <= kSmallEncBytes) small_list[atomicAdd(&tickets[kTicketSmallCount], 1u)] = chunk;
+            else huff_list[atomicAdd(&tickets[kTicketHuffCount], 1u)] = chunk;
+        }
         return;
     }
     encode_stored_chunk<kEncStoredThreads>(in + in_off[chunk], L, n_blocks, my_start, my_end,
@@ -1469,36 +1474,40 @@ __device__ unsigned long long g_enc_times[8];
 // (Round 5, measured and dropped: the kernel as a template -- a one-pass launch for the chunks of one Huffman block, a two-pass launch for the others and
 // for the overflows, handed over through a second list -- so that each has half the code: scratch 76 -> 20 bytes a lane in the one-pass kernel, text
 // 5.66 -> 6.12 ms.  What the scratch holds is read at the head of phases, not in the trips; what the split changed was the allocation inside them.)
-__global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+// kThreads / kOutW: 1 024 threads and a 64 KB staging buffer for every chunk (two workgroups a CU), or -- round 5 -- 256 threads and 16 KB for the
+// chunks of one block and at most kSmallEncBytes bytes (encode_stored_kernel sorts them onto their own list): six workgroups a CU.  A 7 KB file is
+// little work behind a chain of a dozen dependent round trips and barriers, and a CU with two of them in flight mostly waits.
+template <uint32_t kThreads, uint32_t kOutW, uint32_t kMinWaves>
+__global__ __launch_bounds__(kThreads, kMinWaves) void encode_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                 const uint32_t* __restrict__ in_len, const uint2* __restrict__ entries,
                                                                 const uint64_t* __restrict__ sym, const uint64_t* __restrict__ mst,
                                                                 const ChunkInfo* __restrict__ info,
                                                                 const BlockInfo* __restrict__ blocks, const BlockOut* __restrict__ plans,
                                                                 uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ out_len,
                                                                 const uint16_t* __restrict__ links,
-                                                                const uint32_t* __restrict__ huff_list, uint32_t* __restrict__ tickets) {
+                                                                const uint32_t* __restrict__ huff_list, uint32_t* __restrict__ tickets, uint32_t t_count, uint32_t t_next) {
     // Persistent (two workgroups a CU by LDS): the chunks encode_stored_kernel left on the list, handed out by a ticket counter.
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutWords
-    uint32_t* s_queue = reinterpret_cast<uint32_t*>(smem + kOutWords * 4);        // kEncQueue entries per wave (8 KiB): symbol starts waiting for a full trip
-    uint16_t* s_lcode = reinterpret_cast<uint16_t*>(s_queue + (kEncodeThreads / 64) * kEncQueue);   // kMaxBlocks * 288
+    uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);                          // kOutW
+    uint32_t* s_queue = reinterpret_cast<uint32_t*>(smem + kOutW * 4);        // kEncQueue entries per wave (8 KiB): symbol starts waiting for a full trip
+    uint16_t* s_lcode = reinterpret_cast<uint16_t*>(s_queue + (kThreads / 64) * kEncQueue);   // kMaxBlocks * 288
     uint16_t* s_dcode = s_lcode + kMaxBlocks * 288;                               // kMaxBlocks * 32
     uint8_t* s_llen = reinterpret_cast<uint8_t*>(s_dcode + kMaxBlocks * 32);      // kMaxBlocks * 288
     uint8_t* s_dlen = s_llen + kMaxBlocks * 288;                                  // kMaxBlocks * 32
     __shared__ EncBlock s_blk[kMaxBlocks];
-    __shared__ uint32_t s_wsum[kEncodeThreads / 64], s_msum[kEncodeThreads / 64 + 1];
-    __shared__ uint32_t s_total_bytes, s_adler_a[kEncodeThreads / 64];
-    __shared__ unsigned long long s_adler_b[kEncodeThreads / 64];
+    __shared__ uint32_t s_wsum[kThreads / 64], s_msum[kThreads / 64 + 1];
+    __shared__ uint32_t s_total_bytes, s_adler_a[kThreads / 64];
+    __shared__ unsigned long long s_adler_b[kThreads / 64];
 
     __shared__ uint32_t s_item;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_items = tickets[kTicketHuffCount];       // final: encode_stored_kernel has finished
+    const uint32_t n_items = tickets[t_count];                // final: encode_stored_kernel has finished
 #if ZWZ_ENC_EXP & 16
     uint64_t estamp_ = __builtin_amdgcn_s_memtime();
     uint32_t eacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (;;) {
-    if (tid == 0) s_item = atomicAdd(&tickets[kTicketHuffNext], 1u);
+    if (tid == 0) s_item = atomicAdd(&tickets[t_next], 1u);
     __syncthreads();
     const uint32_t item = s_item;
     if (item >= n_items) break;
@@ -1516,7 +1525,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     // contiguous shares -- lane l of wave w holds word w * wpw + l of both masks, the wave's segment below -- so that a short
     // chunk keeps all sixteen waves busy (with fixed 4096-position segments a 7 KB chunk was two waves' work and cost what a
     // 64 KB one did: 4.1 ms per 30 000 image-like files)
-    const uint32_t wpw = (nwords + kEncodeThreads / 64u - 1u) / (kEncodeThreads / 64u);       // words per wave: 64 for a full chunk
+    const uint32_t wpw = (nwords + kThreads / 64u - 1u) / (kThreads / 64u);       // words per wave: 64 for a full chunk
     const uint32_t my_word = (tid >> 6) * wpw + lane_id();
     const bool has_word = lane_id() < wpw && my_word < nwords;
     const uint64_t mst_l = has_word ? gmst[my_word] : 0ull;
@@ -1532,7 +1541,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     }
     for (uint32_t b = 0; b < ci.n_blocks; b++) {
         if (bo[b].type == kStored) continue;   // stored blocks carry no codes (plan may not have built any)
-        for (uint32_t i = tid; i < kLCodes; i += kEncodeThreads) { s_lcode[b * 288 + i] = bo[b].lcode[i]; s_llen[b * 288 + i] = bo[b].llen[i]; }
+        for (uint32_t i = tid; i < kLCodes; i += kThreads) { s_lcode[b * 288 + i] = bo[b].lcode[i]; s_llen[b * 288 + i] = bo[b].llen[i]; }
         if (tid < kDCodes) { s_dcode[b * 32 + tid] = bo[b].dcode[tid]; s_dlen[b * 32 + tid] = bo[b].dlen[tid]; }
     }
     if (tid == 0) {
@@ -1565,9 +1574,9 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         // 4-byte chunk cost: the 10 000 tail chunks of BASELINE configs[1] took 0.2 ms)
         // (a chunk of one Huffman block is packed at private slots first -- below -- whose reach is enc_slot_bits')
         const bool slots = ci.n_blocks == 1u && s_blk[0].type != kStored;
-        const uint32_t reach = slots ? ((s_blk[0].body_pos + 63u) >> 5) + (kEncodeThreads / 64u) * (enc_slot_bits(wpw, s_blk[0].body_pos, s_blk[0].body_bits) >> 5) + 2u : 0u;
-        const uint32_t nz = min(kOutWords, max((s_total_bytes + 3u) / 4u + 2u, reach));
-        for (uint32_t i = tid; i < nz; i += kEncodeThreads) s_out[i] = 0;
+        const uint32_t reach = slots ? ((s_blk[0].body_pos + 63u) >> 5) + (kThreads / 64u) * (enc_slot_bits<kThreads / 64u, kOutW>(wpw, s_blk[0].body_pos, s_blk[0].body_bits) >> 5) + 2u : 0u;
+        const uint32_t nz = min(kOutW, max((s_total_bytes + 3u) / 4u + 2u, reach));
+        for (uint32_t i = tid; i < nz; i += kThreads) s_out[i] = 0;
     }
     __syncthreads();
 
@@ -1575,21 +1584,21 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     // (round 5; see the symbols' block below): the stream's fixed parts then go in behind the symbols, whose waves use the buffer as scratch first.
     const bool one_pass = ci.n_blocks == 1u && s_blk[0].type != kStored && (ZWZ_ENC_EXP & 1) == 0;       // workgroup-uniform
     auto write_headers = [&](bool with_eob) {
-        if (tid == 0) lds_or_bits(s_out, 0, 0x9c78u, 16);
+        if (tid == 0) lds_or_bits<kOutW>(s_out, 0, 0x9c78u, 16);
         for (uint32_t b = 0; b < ci.n_blocks; b++) {
             const EncBlock e = s_blk[b];
             const uint32_t hw = (bo[b].hdr_bits + 31) >> 5;
             if (tid < hw) {
                 uint32_t nb = bo[b].hdr_bits - (tid << 5); if (nb > 32) nb = 32;
                 uint32_t v = bo[b].hdr[tid]; if (nb < 32) v &= (1u << nb) - 1u;
-                lds_or_bits(s_out, (uint64_t)e.hdr_pos + (tid << 5), v, nb);
+                lds_or_bits<kOutW>(s_out, (uint64_t)e.hdr_pos + (tid << 5), v, nb);
             }
             if (tid == 0) {
                 if (e.type == kStored) {
                     const uint32_t len = e.end - e.start;
-                    lds_or_bits(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
+                    lds_or_bits<kOutW>(s_out, e.body_pos, (uint64_t)(len & 0xffffu) | ((uint64_t)(~len & 0xffffu) << 16), 32);
                 } else if (with_eob) {
-                    lds_or_bits(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
+                    lds_or_bits<kOutW>(s_out, (uint64_t)e.body_pos + e.body_bits - e.eob_len, e.eob_code, e.eob_len);
                 }
             }
         }
@@ -1607,13 +1616,13 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         const uint32_t* d32 = reinterpret_cast<const uint32_t*>(data);
 #pragma unroll 1
         for (uint32_t u0 = 0; u0 < 16u; u0 += 4u) {                       // four loads in flight (sixteen pushed this kernel's 64 registers into scratch)
-            if (u0 * kEncodeThreads * 4u >= L) break;                     // (workgroup-uniform: a short chunk has nothing there)
+            if (u0 * kThreads * 4u >= L) break;                     // (workgroup-uniform: a short chunk has nothing there)
             uint32_t w[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = (tid + (u0 + u) * kEncodeThreads) * 4u; w[u] = i < L ? d32[i >> 2] : 0u; }
+            for (uint32_t u = 0; u < 4; u++) { const uint32_t i = (tid + (u0 + u) * kThreads) * 4u; w[u] = i < L ? d32[i >> 2] : 0u; }
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t i = (tid + (u0 + u) * kEncodeThreads) * 4u;
+                const uint32_t i = (tid + (u0 + u) * kThreads) * 4u;
                 uint32_t x = w[u];
                 if (i < L && i + 4u > L) x &= (1u << (8u * (L - i))) - 1u;
                 const uint32_t sum = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false), ramp = __builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
@@ -1625,7 +1634,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         for (uint32_t b = 0; b < ci.n_blocks; b++) {
             if (s_blk[b].type != kStored) continue;
             const uint32_t st0 = s_blk[b].start, len = s_blk[b].end - st0, ob0 = s_blk[b].data_byte;
-            for (uint32_t i = tid; i < len; i += kEncodeThreads) if (ob0 + i < kOutWords * 4) s_out8[ob0 + i] = data[st0 + i];
+            for (uint32_t i = tid; i < len; i += kThreads) if (ob0 + i < kOutW * 4) s_out8[ob0 + i] = data[st0 + i];
         }
     }
     {
@@ -1737,14 +1746,14 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
         // passes below (never on the corpora).
         bool two_pass = !one_pass;
         if (one_pass) {
-            const uint32_t slot_bits = enc_slot_bits(wpw, s_blk[0].body_pos, s_blk[0].body_bits), slot0 = (s_blk[0].body_pos + 63u) & ~31u;
+            const uint32_t slot_bits = enc_slot_bits<kThreads / 64u, kOutW>(wpw, s_blk[0].body_pos, s_blk[0].body_bits), slot0 = (s_blk[0].body_pos + 63u) & ~31u;
             const uint32_t q = slot0 + wave * slot_bits;                                       // a multiple of 32
             uint32_t running = 0;
             for_each_trip([&](uint32_t ent, uint32_t byte, uint32_t rec, bool live) {
                 uint64_t v = 0; uint32_t nb = 0;
                 if (live) symbol_bits(s_lcode, s_llen, s_dcode, s_dlen, rec, byte, v, nb);
                 const uint32_t incl = wave_scan_incl(nb);
-                if (nb) lds_or_bits(s_out, (uint64_t)q + (running + incl - nb), v, nb);
+                if (nb) lds_or_bits<kOutW>(s_out, (uint64_t)q + (running + incl - nb), v, nb);
                 running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             });
             if (lane == 0) s_wsum[wave] = running;
@@ -1752,9 +1761,9 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             __syncthreads();
             ZWZ_ESTAMP(4);
             // lane i < 16: wave i's bits; the scan gives every wave all sixteen starts
-            const uint32_t m_l = lane < kEncodeThreads / 64u ? s_wsum[lane] : 0u;
+            const uint32_t m_l = lane < kThreads / 64u ? s_wsum[lane] : 0u;
             pre_l = wave_scan_incl(m_l) - m_l;                                                 // lane 16: all the symbols' bits
-            const bool fits = __builtin_amdgcn_ballot_w64(m_l > slot_bits) == 0 && slot0 + (kEncodeThreads / 64u) * slot_bits + 64u <= kOutWords * 32u;   // (.. and the slots themselves fit the buffer)
+            const bool fits = __builtin_amdgcn_ballot_w64(m_l > slot_bits) == 0 && slot0 + (kThreads / 64u) * slot_bits + 64u <= kOutW * 32u;   // (.. and the slots themselves fit the buffer)
             if (fits) {
                 // The slots stay where they are: the stream is put together on its way OUT (below) -- a word of it is the header's bits (in front of
                 // the first slot, written above), at most a few slots' bits funnel-shifted to where the wave totals say they belong, the end-of-block
@@ -1763,12 +1772,12 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
                 // resp. nine barriers and 14 k LDS atomics a chunk: 7.32 and 7.12 ms on text against the two passes' 8.33.  And between barriers
                 // a workgroup is sixteen waves each running a short serial piece at an eighth of a SIMD: the prefix over the wave totals by
                 // seventeen lanes and the checksum's last step by one thread -- two barriers -- were 40 k cycles a chunk.)
-                if (lane <= kEncodeThreads / 64u) s_msum[lane] = pre_l;                         // every wave writes the same seventeen words and reads back its own: no barrier
+                if (lane <= kThreads / 64u) s_msum[lane] = pre_l;                         // every wave writes the same seventeen words and reads back its own: no barrier
                 in_slots = true;
                         } else {
                 two_pass = true;                                                               // workgroup-uniform: s_wsum is everybody's
                 __syncthreads();
-                for (uint32_t i = tid; i < kOutWords; i += kEncodeThreads) s_out[i] = 0;
+                for (uint32_t i = tid; i < kOutW; i += kThreads) s_out[i] = 0;
                 __syncthreads();
                 write_headers(true);
             }
@@ -1799,7 +1808,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             const uint32_t incl = wave_scan_incl(nb);
             if (nb) {
                 const EncBlock& eb = s_blk[blk];
-                lds_or_bits(s_out, (uint64_t)eb.body_pos + (running + incl - nb - eb.sym_bits_before), v, nb);
+                lds_or_bits<kOutW>(s_out, (uint64_t)eb.body_pos + (running + incl - nb - eb.sym_bits_before), v, nb);
             }
             running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         });
@@ -1810,7 +1819,7 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     // Adler-32 of the raw chunk: a = 1 + sum d_i, b = L + sum (L - i) d_i   (mod 65521)
     auto adler_be = [&]() -> uint32_t {
         unsigned long long a = 1, b = L;
-        for (uint32_t i = 0; i < kEncodeThreads / 64; i++) { a += s_adler_a[i]; b += s_adler_b[i]; }
+        for (uint32_t i = 0; i < kThreads / 64; i++) { a += s_adler_a[i]; b += s_adler_b[i]; }
         return __builtin_bswap32((uint32_t)((b % 65521ull) << 16) | (uint32_t)(a % 65521ull));
     };
     const uint32_t n_out = s_total_bytes < kChunk ? s_total_bytes : kChunk;
@@ -1818,25 +1827,25 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
     if (tid == 0) out_len[chunk] = n_out;
     if (!in_slots) {
         __syncthreads();
-        if (tid == 0) lds_or_bits(s_out, 8ull * (s_total_bytes - 4), adler_be(), 32);
+        if (tid == 0) lds_or_bits<kOutW>(s_out, 8ull * (s_total_bytes - 4), adler_be(), 32);
         __syncthreads();
     }
     ZWZ_ESTAMP(6);                                            // waiting for the other waves, the checksum
     if (!in_slots) {
-        for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kEncodeThreads) gout[i] = s_out[i];
+        for (uint32_t i = tid; i < ((n_out + 3) >> 2); i += kThreads) gout[i] = s_out[i];
     } else {
         // word j of the stream = bits [32 j, 32 j + 32): header words as they lie; of the symbols, slot w holds bits [body + msum[w], + wsum[w]) from its own first bit on
-        const uint32_t body = s_blk[0].body_pos, slot_bits = enc_slot_bits(wpw, body, s_blk[0].body_bits), slot0 = (body + 63u) & ~31u;
-        const uint32_t sym_end = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, kEncodeThreads / 64u);
+        const uint32_t body = s_blk[0].body_pos, slot_bits = enc_slot_bits<kThreads / 64u, kOutW>(wpw, body, s_blk[0].body_bits), slot0 = (body + 63u) & ~31u;
+        const uint32_t sym_end = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, kThreads / 64u);
         const uint32_t eob_code = s_blk[0].eob_code, ad_pos = 8u * (s_total_bytes - 4u);
-        uint32_t d_of[kEncodeThreads / 64u];                  // (scalar registers: the same for every lane)
+        uint32_t d_of[kThreads / 64u];                  // (scalar registers: the same for every lane)
 #pragma unroll
-        for (uint32_t i = 0; i < kEncodeThreads / 64u; i++) d_of[i] = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, i);
+        for (uint32_t i = 0; i < kThreads / 64u; i++) d_of[i] = body + (uint32_t)__builtin_amdgcn_readlane((int)pre_l, i);
         auto piece = [](uint32_t pos, uint32_t val, uint32_t bit) -> uint32_t {       // of val laid down at bit `pos`, what falls into [bit, bit + 32)
             const int d = (int)pos - (int)bit;
             return d >= 32 || d <= -32 ? 0u : d >= 0 ? val << d : val >> (-d);
         };
-        for (uint32_t j = tid; j < ((n_out + 3) >> 2); j += kEncodeThreads) {
+        for (uint32_t j = tid; j < ((n_out + 3) >> 2); j += kThreads) {
             const uint32_t bit = j << 5;
             uint32_t v = j < (slot0 >> 5) ? s_out[j] : 0u;
             v |= piece(sym_end, eob_code, bit);
@@ -1844,8 +1853,8 @@ __global__ __launch_bounds__(kEncodeThreads, 8) void encode_kernel(const uint8_t
             if (bit + 32u > body && bit < sym_end) {
                 uint32_t w = 0;                               // the slot bit `bit` falls into (the first one for the header's last word)
 #pragma unroll
-                for (uint32_t i = 1; i < kEncodeThreads / 64u; i++) w += d_of[i] <= bit ? 1u : 0u;
-                for (; w < kEncodeThreads / 64u; w++) {
+                for (uint32_t i = 1; i < kThreads / 64u; i++) w += d_of[i] <= bit ? 1u : 0u;
+                for (; w < kThreads / 64u; w++) {
                     const uint32_t d = body + s_msum[w];
                     if (d >= bit + 32u) break;
                     const int sft = (int)bit - (int)d, len = (int)s_wsum[w];
@@ -2556,7 +2565,8 @@ hipError_t configure_kernels() {
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(exchange_order_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinksLdsBytes));
     ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lz_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMatchLdsBytes));
-    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<kEncodeThreads, kOutWords, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncodeLdsBytes));
+    ZWZ_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<kSmallEncThreads, kSmallEncOutWords, kSmallEncWgs>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallEncLdsBytes));
     ZWZ_TRY(configure_lazy_kernels());
     return configure_band_kernels();
 }
@@ -2621,11 +2631,14 @@ hipError_t launch_deflate(const DeflateArgs& a, hipStream_t s, hipEvent_t* ev /*
     if (ev) ZWZ_TRY(hipEventRecord(ev[5], s));
     {
         uint32_t* huff_list = reinterpret_cast<uint32_t*>(a.perm);          // lz_match's work-order array is dead by now
+        uint32_t* small_list = huff_list + a.n;                             // (plan's list of open blocks is dead too)
         hipLaunchKernelGGL(encode_stored_kernel, dim3(a.n), dim3(kEncStoredThreads), 0, s, a.in, a.in_off, a.in_len, a.info, a.blocks, a.plans,
-                           a.out, a.out_stride, a.out_len, huff_list, a.tickets);
-        const uint32_t slots = 2u * (a.cu_count ? a.cu_count : 256u);
-        hipLaunchKernelGGL(encode_kernel, dim3(a.n < slots ? a.n : slots), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
-                           a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links, huff_list, a.tickets);
+                           a.out, a.out_stride, a.out_len, huff_list, small_list, a.tickets);
+        const uint32_t cus = a.cu_count ? a.cu_count : 256u;
+        hipLaunchKernelGGL((encode_kernel<kEncodeThreads, kOutWords, 8>), dim3(a.n < 2u * cus ? a.n : 2u * cus), dim3(kEncodeThreads), kEncodeLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
+                           a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links, huff_list, a.tickets, (uint32_t)kTicketHuffCount, (uint32_t)kTicketHuffNext);
+        hipLaunchKernelGGL((encode_kernel<kSmallEncThreads, kSmallEncOutWords, kSmallEncWgs>), dim3(a.n < kSmallEncWgs * cus ? a.n : kSmallEncWgs * cus), dim3(kSmallEncThreads), kSmallEncLdsBytes, s, a.in, a.in_off, a.in_len, a.entries, a.sym,
+                           a.mst, a.info, a.blocks, a.plans, a.out, a.out_stride, a.out_len, a.links, small_list, a.tickets, (uint32_t)kTicketSmallCount, (uint32_t)kTicketSmallNext);
     }
 #if ZWZ_ENC_EXP & 16
     if (getenv("ZWZ_ENC_TIMES")) {
